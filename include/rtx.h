@@ -1,0 +1,218 @@
+/*
+ * rtx.h — C-ABI of the MI355X-native HIP render backend for RayTracer's
+ * frame-render hot path (IFrameRender::Render(Color*)).
+ *
+ * Every entry point is plain C: pointers, sizes, PODs. No torch / C++ types.
+ * File:line citations are relative to the reference tree (DavidSolz/RayTracer).
+ *
+ * The POD structs below restate the reference's host layouts byte for byte
+ * (sizes and offsets are static-asserted in raytracer_amd/csrc/rtx_layout_check.cpp)
+ * so that a HIPShader : ComputeShader inside the reference can pass
+ * context->objects.data() etc. straight through.
+ *
+ * Return convention: 0 = ok, non-zero = error (message via rtx_last_error()).
+ * The reference's own convention is void + log + exit(-1)
+ * (src/ComputeEnvironment.cpp:129-132); the C++ wrapper maps non-zero to that.
+ * All functions are to be called from one thread per renderer (the reference
+ * calls Render strictly sequentially from the main thread,
+ * src/WindowManager.cpp:154-158).
+ */
+#ifndef RTX_H
+#define RTX_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- reference POD layouts ------------------------------------------------ */
+
+/* src/Vector3.h:7-201 and src/Color.h:9-145 — four floats, 16-byte aligned. */
+typedef struct RtxVec4 { float x, y, z, w; } __attribute__((aligned(16))) RtxVec4;
+
+/* src/SpatialType.h:7-15 */
+enum { RTX_SPHERE = 0, RTX_PLANE = 1, RTX_DISK = 2, RTX_CUBE = 3, RTX_TRIANGLE = 4, RTX_INVALID = 5 };
+
+/* src/Object.h:11-19 — 256 bytes: type@0 radius@4 position@16 normals@32
+ * vertices@80 uvs@128 materialID@176. */
+typedef struct RtxObject {
+    int32_t type;
+    float   radius;
+    float   _pad0[2];
+    RtxVec4 position;
+    RtxVec4 normals[3];
+    RtxVec4 vertices[3];
+    RtxVec4 uvs[3];
+    int32_t materialID;
+    int32_t _pad1[19];
+} __attribute__((aligned(256))) RtxObject;
+
+/* src/Material.h:7-25 — 128 bytes. */
+typedef struct RtxMaterial {
+    RtxVec4 albedo;              /*   0 */
+    RtxVec4 tint;                /*  16 */
+    RtxVec4 specular;            /*  32 */
+    RtxVec4 transmissionFilter;  /*  48 */
+    float   specularIntensity;   /*  64 */
+    float   transparency;        /*  68 */
+    float   indexOfRefraction;   /*  72 */
+    float   roughness;           /*  76 */
+    float   metallic;            /*  80 */
+    float   sheen;               /*  84 */
+    float   tintRoughness;       /*  88 */
+    float   clearcoatThickness;  /*  92 */
+    float   clearcoatRoughness;  /*  96 */
+    float   emmissionIntensity;  /* 100 (sic) */
+    float   anisotropy;          /* 104 */
+    float   anisotropyRotation;  /* 108 */
+    int32_t textureID;           /* 112 */
+    int32_t _pad[3];
+} __attribute__((aligned(128))) RtxMaterial;
+
+/* src/BoundingBox.h:7-48 — 64 bytes; leaf <=> objectID != -1. */
+typedef struct RtxBoundingBox {
+    int32_t objectID;
+    int32_t parentID;
+    int32_t leftID;
+    int32_t rightID;
+    RtxVec4 minimalPosition;
+    RtxVec4 maximalPosition;
+    int32_t _pad[4];
+} __attribute__((aligned(64))) RtxBoundingBox;
+
+/* src/Texture.h:4-9 */
+typedef struct RtxTexture {
+    int32_t  width;
+    int32_t  height;
+    int32_t  offset;    /* first texel, in uint32 words, inside textureData */
+    uint32_t checksum;
+} __attribute__((aligned(16))) RtxTexture;
+
+/* src/Camera.h:9-65 — 96 bytes. */
+typedef struct RtxCamera {
+    RtxVec4 front;          /*  0 */
+    RtxVec4 up;             /* 16 */
+    RtxVec4 right;          /* 32 */
+    RtxVec4 position;       /* 48 */
+    float   movementSpeed;  /* 64 */
+    float   rotationSpeed;  /* 68 */
+    float   aspectRatio;    /* 72 */
+    float   nearView;       /* 76 */
+    float   farView;        /* 80 */
+    float   fov;            /* 84 */
+    float   pitch;          /* 88 */
+    float   yaw;            /* 92 */
+} RtxCamera;
+
+/* ---- scene hand-over ------------------------------------------------------- */
+
+/* Borrowed pointers to the five host arrays of src/RenderingContext.h:31-40 in
+ * their reference layouts, read once by rtx_create (precedent: the OpenCL
+ * backend uploads them once in its constructor, src/CLShader.cpp:20-49). */
+typedef struct RtxSceneDesc {
+    const RtxObject*      objects;      uint64_t numObjects;
+    const RtxMaterial*    materials;    uint64_t numMaterials;
+    const RtxBoundingBox* boxes;        uint64_t numBoxes;     /* 2N-1, pre-order; may be 0 */
+    const RtxTexture*     textureInfo;  uint64_t numTextures;
+    const uint32_t*       textureData;  uint64_t numTexels;
+    uint32_t width;                     /* context->width  */
+    uint32_t height;                    /* context->height */
+    int32_t  useBVH;                    /* context->bvhAcceleration (src/ThreadedShader.cpp:15-19) */
+    int32_t  _pad;
+} RtxSceneDesc;
+
+enum { RTX_TRAVERSE_CULLED = 0,   /* near-first, distance-culled; same closest hit + tie-break  */
+       RTX_TRAVERSE_EXACT  = 1 }; /* reference visit set: no distance culling at all            */
+
+typedef struct RtxConfig {
+    int32_t device;        /* HIP device ordinal */
+    int32_t rank;          /* this process' share of the screen tiles ...            */
+    int32_t worldSize;     /* ... tile t is owned by rank (t % worldSize)            */
+    int32_t tileW;         /* screen tile size in pixels; 0 -> 64                    */
+    int32_t tileH;         /*                             0 -> 32                    */
+    int32_t traversal;     /* RTX_TRAVERSE_*                                         */
+    int32_t countStats;    /* 1: count node/leaf visits per frame (slower kernels)   */
+    int32_t _pad;
+} RtxConfig;
+
+typedef struct RtxCounters {
+    uint64_t frames;          /* rtx_render* calls since create / reset                    */
+    uint64_t rays;            /* closest-hit queries issued (primary + bounce)             */
+    uint64_t raysPerBounce[4];
+    uint64_t hitsPerBounce[4];
+    uint64_t innerVisits;     /* inner-node records fetched   (countStats only)            */
+    uint64_t leafTests;       /* leaf primitives intersected  (countStats only)            */
+    double   lastFrameMs;     /* device time of the last rtx_render* call (HIP events)     */
+    double   lastTraceMs;     /* ... of which traversal kernels                            */
+    double   lastShadeMs;     /* ... of which shading kernels                              */
+    double   totalMs;         /* sum of lastFrameMs                                        */
+} RtxCounters;
+
+typedef struct RtxRenderer RtxRenderer;
+
+/* ---- the hot path ----------------------------------------------------------- */
+
+/* Replaces: ThreadedShader::ThreadedShader (src/ThreadedShader.cpp:4-21) /
+ * CLShader::CLShader (src/CLShader.cpp:6-69): bind to a RenderingContext's
+ * arrays. Flattens boxes+objects into the SoA device layout, uploads materials
+ * and textures, allocates the resident framebuffer (zero-filled like
+ * src/WindowManager.cpp:26-27) and the ray queues. */
+int rtx_create(const RtxSceneDesc* scene, const RtxConfig* cfg, RtxRenderer** out);
+
+/* Replaces: IFrameRender::Render(Color* _pixels) (src/IFrameRender.h:8,
+ * src/ThreadedShader.cpp:186-207). Reads camera + frameCounter per call like
+ * src/CLShader.cpp:160-166. pixels_rgba: host, width*height*4 floats, row-major
+ * y*width+x; may be NULL to skip the device-to-host copy (the running mean
+ * stays resident on the device either way). With worldSize > 1 only this
+ * rank's tiles are written; other pixels of pixels_rgba are left untouched. */
+int rtx_render(RtxRenderer* r, const RtxCamera* camera, uint32_t frameCounter, float* pixels_rgba);
+
+/* Parity probe for ThreadedShader::BVHTraverse / LinearTraverse on primary rays
+ * (src/ThreadedShader.cpp:141-149,158): objectIDs[y*width+x] = sample.objectID
+ * of the first traverse() of frame `frameCounter` (-1 = miss). Host buffer. */
+int rtx_primary_hits(RtxRenderer* r, const RtxCamera* camera, uint32_t frameCounter, int32_t* objectIDs);
+
+/* Parity probe for traverse() on caller-supplied rays (bounce-like, incoherent):
+ * origins/directions are n*4 floats (x,y,z,ignored). Outputs (host, each may be
+ * NULL): objectIDs[n], points[n*4] (sample.point), normals[n*4]. */
+int rtx_trace_rays(RtxRenderer* r, const float* origins, const float* directions, uint64_t n,
+                   int32_t* objectIDs, float* points, float* normals);
+
+/* Overwrite / read the resident running-mean framebuffer (the reference's
+ * `pixels`, src/WindowManager.cpp:26-27). */
+int rtx_upload_pixels(RtxRenderer* r, const float* pixels_rgba);
+int rtx_download_pixels(RtxRenderer* r, float* pixels_rgba);
+int rtx_clear_pixels(RtxRenderer* r);
+
+int  rtx_get_counters(RtxRenderer* r, RtxCounters* out);
+int  rtx_reset_counters(RtxRenderer* r);
+void rtx_destroy(RtxRenderer* r);
+const char* rtx_last_error(void);
+
+/* ---- multi-GPU tile plumbing (no reference counterpart: new work) */
+
+/* Device pointer of the resident framebuffer (width*height float4, row-major). */
+void*    rtx_framebuffer_device_ptr(RtxRenderer* r);
+/* The HIP stream every kernel of this renderer is launched on (hipStream_t). */
+void*    rtx_stream(RtxRenderer* r);
+/* Number of pixels this rank owns / number of tiles it owns. */
+uint64_t rtx_local_pixel_count(RtxRenderer* r);
+uint32_t rtx_local_tile_count(RtxRenderer* r);
+/* Floats needed by a packed tile buffer of `rank` (tileCount*tileW*tileH*4). */
+uint64_t rtx_packed_floats(RtxRenderer* r, int32_t rank);
+/* Pack this rank's tiles from the resident framebuffer into d_packed (device,
+ * tile-major: tile k of this rank at k*tileW*tileH float4, row-major inside). */
+int rtx_pack_tiles(RtxRenderer* r, void* d_packed);
+/* Scatter a packed tile buffer that belongs to `srcRank` into the resident
+ * framebuffer of this renderer (used on the gathering rank). */
+int rtx_unpack_tiles(RtxRenderer* r, const void* d_packed, int32_t srcRank);
+
+/* ---- build info -------------------------------------------------------------- */
+const char* rtx_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTX_H */

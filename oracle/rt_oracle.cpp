@@ -1,0 +1,731 @@
+/*
+ * rt_oracle.cpp — CPU restatement of RayTracer's frame-render hot path
+ * (ThreadedShader::Render and everything below it).
+ *
+ * THIS IS TEST INFRASTRUCTURE. Only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg may build, load or call it. The product path
+ * (raytracer_amd/, include/rtx.h) never links or calls anything in oracle/.
+ *
+ * Every function cites the reference file:line it follows (paths relative to
+ * the reference tree). The arithmetic is restated operation by operation,
+ * including the places where the reference's unqualified libm calls resolve to
+ * the *double* overloads, where macros expand unparenthesised, and the SSE
+ * min/max NaN rule. It must be compiled strict:
+ *     g++ -O2 -ffp-contract=off -fno-fast-math   (see oracle/Makefile)
+ *
+ * Pinning (see DESIGN.md "Oracle"):
+ *   - the reference's ThreadedShader.cpp cannot be compiled in this image
+ *     (src/RenderingContext.h:10-11 needs GL/glew.h and GLFW/glfw3.h, which
+ *     are absent, and stand-in headers are not allowed), so the functions that
+ *     live in ThreadedShader.cpp are pinned by the reference outputs recorded in
+ *     BASELINE.md §2 (primary-hit count and ID-map hash of 2.scn at 992x992,
+ *     strict build) — tests/test_oracle_pins.py;
+ *   - the header-only part of the path (Shading.h, Camera.h, Vector3.h, Color.h)
+ *     and Random.cpp DO compile standalone; oracle/ref_parts.cpp builds them
+ *     from /root/reference into oracle/_ref/ and tests/test_oracle_vs_ref_parts.py
+ *     checks this file against them bit for bit.
+ *
+ * Deviations from the reference, all confined to places where the reference
+ * itself has undefined behaviour:
+ *   - texel indices are clamped into [0, numTexels + tail padding) and the tail
+ *     padding reads as 0 (the reference reads past the vector end,
+ *     src/Shading.h:170-173);
+ *   - (int)NaN is taken as INT_MIN like x86 cvttss2si, then clamped as above.
+ */
+#include "../include/rtx.h"
+
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <cstdlib>
+#include <thread>
+#include <vector>
+#include <atomic>
+
+namespace {
+
+// ---------------------------------------------------------------------------
+// 4-lane float value mirroring the reference's SSE-backed Vector3 / Color
+// (src/Vector3.h:93-174, src/Color.h:15-78): +,-,* act on all four lanes.
+// ---------------------------------------------------------------------------
+struct F4 { float x, y, z, w; };
+
+inline F4 f4(float x, float y, float z, float w = 0.0f) { return F4{x, y, z, w}; }
+inline F4 from(const RtxVec4& v) { return F4{v.x, v.y, v.z, v.w}; }
+inline F4 add(F4 a, F4 b) { return F4{a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w}; }
+inline F4 sub(F4 a, F4 b) { return F4{a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w}; }
+inline F4 mul(F4 a, F4 b) { return F4{a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w}; }
+inline F4 mul(F4 a, float s) { return F4{a.x * s, a.y * s, a.z * s, a.w * s}; }
+
+// _mm_min_ps / _mm_max_ps: result = (a OP b) ? a : b, i.e. the SECOND operand
+// when either is NaN (src/Vector3.h:54-91, src/Color.h:109-122).
+inline float sse_min(float a, float b) { return a < b ? a : b; }
+inline float sse_max(float a, float b) { return a > b ? a : b; }
+inline F4 sse_min(F4 a, F4 b) { return F4{sse_min(a.x, b.x), sse_min(a.y, b.y), sse_min(a.z, b.z), sse_min(a.w, b.w)}; }
+inline F4 sse_max(F4 a, F4 b) { return F4{sse_max(a.x, b.x), sse_max(a.y, b.y), sse_max(a.z, b.z), sse_max(a.w, b.w)}; }
+
+// src/Vector3.h:34-36
+inline float dot(F4 a, F4 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+// src/Vector3.h:42-47 (result w = 0)
+inline F4 cross(F4 a, F4 b) {
+    float nX = a.y * b.z - b.y * a.z;
+    float nY = -(a.x * b.z - b.x * a.z);
+    float nZ = a.x * b.y - b.x * a.y;
+    return f4(nX, nY, nZ);
+}
+// src/Vector3.h:152-162 — operator/(scalar) multiplies by 1.0f/scalar
+inline F4 divs(F4 a, float s) { return mul(a, 1.0f / s); }
+// src/Vector3.h:184-199 — magnitude over xyz only, all four lanes scaled
+inline F4 normalize(F4 a) { return divs(a, sqrtf(dot(a, a))); }
+// src/Vector3.h:49-52 — t is clamped with the double fmax/fmin (NaN -> 1)
+inline float clamp01_libm(float t) { return (float)fmax(0.0f, fmin(t, 1.0f)); }
+inline F4 lerp_v(F4 a, F4 b, float t_clamped) { return add(a, mul(sub(b, a), t_clamped)); }
+// src/Vector3.h:78-91, src/Color.h:109-122
+inline F4 clamp01_sse(F4 a) { return sse_max(sse_min(a, f4(1, 1, 1, 1)), f4(0, 0, 0, 0)); }
+// src/Color.h:95-98 (std::fmax/std::fmin float overloads)
+inline F4 lerp_c(F4 a, F4 b, float t) {
+    float scale = std::fmax(0.0f, std::fmin(t, 1.0f));
+    return add(a, mul(sub(b, a), scale));
+}
+
+const F4 WHITE = {1.0f, 1.0f, 1.0f, 1.0f};              // src/Color.h:147
+#define PI_F 3.1415926535f
+const float ONE_OVER_UCHAR_MAX = 1.0f / 255.0f;          // src/Color.h:7
+
+// ---------------------------------------------------------------------------
+// Scene view
+// ---------------------------------------------------------------------------
+struct Scene {
+    const RtxObject* objects;   uint64_t numObjects;
+    const RtxMaterial* materials; uint64_t numMaterials;
+    const RtxBoundingBox* boxes; uint64_t numBoxes;
+    const RtxTexture* textureInfo; uint64_t numTextures;
+    const uint32_t* textureData; uint64_t numTexels;
+    uint32_t width, height;
+    int useBVH;
+};
+
+struct Ray { F4 origin, direction; };
+struct Sample { F4 point; int objectID; };
+struct Stats { uint64_t inner, leaf; };
+
+// ---------------------------------------------------------------------------
+// src/Random.cpp:3-7
+// ---------------------------------------------------------------------------
+inline float Rand(uint32_t& seed) {
+    seed = seed * 747796405u + 2891336453u;
+    uint32_t word = ((seed >> 17) ^ seed) * 277803737u;
+    return ((word >> 22u) ^ word) / (float)__UINT32_MAX__;
+}
+
+// src/ThreadedShader.cpp:23-35 with the macros of src/Random.h:4-5 expanded:
+// acos is the double overload; "- PI_HALF" is "- 3.1415926535f * 0.5f".
+inline F4 RandomDirection(uint32_t& seed) {
+    float latitude = (float)(acos((double)(2.0f * Rand(seed) - 1.0f)) - (double)(PI_F * 0.5f));
+    float longitude = Rand(seed) * 2.0f * PI_F;
+    float cosLatitude = cosf(latitude);
+    return f4(cosLatitude * cosf(longitude), cosLatitude * sinf(longitude), sinf(latitude));
+}
+
+// src/Camera.h:57-64
+inline F4 CalculatePixelPosition(const RtxCamera& c, int x, int y, int width, int height) {
+    float tanHalfFOV = (float)tan((double)(0.0174532925f * c.fov * 0.5f));
+    float cameraX = (float)((2.0 * x / (float)width - 1.0f) * c.aspectRatio * tanHalfFOV * c.nearView);
+    float cameraY = (float)((2.0 * y / (float)height - 1.0f) * tanHalfFOV * c.nearView);
+    F4 p = add(from(c.position), mul(from(c.front), c.nearView));
+    p = add(p, mul(from(c.right), cameraX));
+    p = add(p, mul(from(c.up), cameraY));
+    return p;
+}
+
+// src/ThreadedShader.cpp:141-149
+inline Ray PrimaryRay(const Scene& s, const RtxCamera& cam, uint32_t fc, int x, int y, uint32_t& seed) {
+    uint32_t index = (uint32_t)(y * (int)s.width + x);
+    seed = (fc << 16) ^ ((fc >> 13) + index);
+    F4 offset = RandomDirection(seed);
+    F4 pixelPosition = CalculatePixelPosition(cam, (int)(x + offset.x), (int)(y + offset.y), (int)s.width, (int)s.height);
+    Ray ray;
+    ray.origin = from(cam.position);
+    ray.direction = normalize(sub(pixelPosition, ray.origin));
+    return ray;
+}
+
+// src/ThreadedShader.cpp:275-289
+inline bool AABBIntersection(const Ray& ray, F4 lo, F4 hi) {
+    F4 inv = f4(1.0f / ray.direction.x, 1.0f / ray.direction.y, 1.0f / ray.direction.z);
+    F4 tMin = mul(sub(lo, ray.origin), inv);
+    F4 tMax = mul(sub(hi, ray.origin), inv);
+    F4 t1 = sse_min(tMin, tMax);
+    F4 t2 = sse_max(tMin, tMax);
+    float tNear = (float)fmax(t1.x, fmax(t1.y, t1.z));
+    float tFar = (float)fmin(t2.x, fmin(t2.y, t2.z));
+    return tNear <= tFar && tFar > 0.0f;
+}
+
+// src/ThreadedShader.cpp:291-321
+inline float IntersectTriangle(const Ray& ray, const RtxObject& o) {
+    const float epsilon = 1e-6f;
+    F4 A = from(o.vertices[0]), B = from(o.vertices[1]), C = from(o.vertices[2]);
+    F4 e1 = sub(B, A);
+    F4 e2 = sub(C, A);
+    F4 normal = cross(ray.direction, e2);
+    float det = dot(e1, normal);
+    if (fabs(det) < epsilon) return -1.0f;
+    float f = 1.0f / det;
+    F4 rayToTriangle = sub(ray.origin, A);
+    float u = f * dot(rayToTriangle, normal);
+    if (u < 0.0f || u > 1.0f) return -1.0f;
+    F4 q = cross(rayToTriangle, e1);
+    float v = f * dot(ray.direction, q);
+    if (v < 0.0f || (u + v) > 1.0f) return -1.0f;
+    return f * dot(e2, q);
+}
+
+// src/ThreadedShader.cpp:323-335
+inline float IntersectSphere(const Ray& ray, const RtxObject& o) {
+    F4 oc = sub(ray.origin, from(o.position));
+    float b = dot(oc, ray.direction);
+    float c = dot(oc, oc) - o.radius * o.radius;
+    float delta = b * b - c;
+    float sqrtDelta = std::sqrt(delta);
+    float t1 = (-b - sqrtDelta);
+    float t2 = (-b + sqrtDelta);
+    return (float)fmin(t1, t2);
+}
+
+inline float Intersect(const Ray& ray, const RtxObject& o) {
+    return o.type == RTX_TRIANGLE ? IntersectTriangle(ray, o) : IntersectSphere(ray, o);
+}
+
+// src/ThreadedShader.cpp:400-428 == :242-270
+inline void HitNormal(const RtxObject& o, F4 point, F4& normal) {
+    if (o.type == RTX_SPHERE) {
+        normal = normalize(sub(point, from(o.position)));
+    } else if (o.type == RTX_TRIANGLE) {
+        F4 A = from(o.vertices[0]), B = from(o.vertices[1]), C = from(o.vertices[2]);
+        F4 v0 = sub(B, A), v1 = sub(C, A), v2 = sub(point, A);
+        float dot00 = dot(v0, v0), dot01 = dot(v0, v1), dot02 = dot(v0, v2);
+        float dot11 = dot(v1, v1), dot12 = dot(v1, v2);
+        float invDenom = 1.0f / (dot00 * dot11 - dot01 * dot01);
+        float u = (dot11 * dot02 - dot01 * dot12) * invDenom;
+        float v = (dot00 * dot12 - dot01 * dot02) * invDenom;
+        float w = 1.0f - u - v;
+        normal = normalize(add(add(mul(from(o.normals[0]), w), mul(from(o.normals[1]), u)), mul(from(o.normals[2]), v)));
+    }
+}
+
+// src/ThreadedShader.cpp:337-431. The reference's stack is int[32]
+// (src/ThreadedShader.h:23); a deeper tree is undefined behaviour there, here
+// the stack simply grows. `stats` counts inner-node expansions and leaf tests
+// (the reference-semantics I and L of SURVEY.md §8d).
+Sample BVHTraverse(const Scene& s, const Ray& ray, F4& normal, Stats* stats) {
+    Sample sample{}; sample.objectID = -1;
+    float minLength = INFINITY;
+    int stackBuf[128]; int size = 0;
+    stackBuf[size++] = 0;
+    while (size > 0) {
+        int boxID = stackBuf[--size];
+        const RtxBoundingBox& box = s.boxes[boxID];
+        if (box.objectID != -1) {
+            if (stats) stats->leaf++;
+            const RtxObject& object = s.objects[box.objectID];
+            float length = Intersect(ray, object);
+            if ((length < minLength) && (length > 0.01f)) {
+                minLength = length;
+                sample.point = add(ray.origin, mul(ray.direction, length));
+                sample.objectID = box.objectID;
+            }
+        } else {
+            if (stats) stats->inner++;
+            if (box.leftID != -1) {
+                const RtxBoundingBox& l = s.boxes[box.leftID];
+                if (AABBIntersection(ray, from(l.minimalPosition), from(l.maximalPosition)) && size < 127) stackBuf[size++] = box.leftID;
+            }
+            if (box.rightID != -1) {
+                const RtxBoundingBox& r = s.boxes[box.rightID];
+                if (AABBIntersection(ray, from(r.minimalPosition), from(r.maximalPosition)) && size < 127) stackBuf[size++] = box.rightID;
+            }
+        }
+    }
+    if (sample.objectID < 0) return sample;
+    HitNormal(s.objects[sample.objectID], sample.point, normal);
+    return sample;
+}
+
+// src/ThreadedShader.cpp:209-273 (EPSILON = 1.0000001f, src/ThreadedShader.h:22)
+Sample LinearTraverse(const Scene& s, const Ray& ray, F4& normal, Stats* stats) {
+    Sample sample{}; sample.objectID = -1;
+    float minLength = INFINITY;
+    F4 scaledDir = mul(ray.direction, 1.0000001f);
+    for (int id = 0; id < (int)s.numObjects; ++id) {
+        if (stats) stats->leaf++;
+        float length = Intersect(ray, s.objects[id]);
+        if ((length < minLength) && (length > 0.01f)) {
+            minLength = length;
+            sample.point = add(ray.origin, mul(scaledDir, length));
+            sample.objectID = id;
+        }
+    }
+    if (sample.objectID == -1) return sample;
+    HitNormal(s.objects[sample.objectID], sample.point, normal);
+    return sample;
+}
+
+inline Sample Traverse(const Scene& s, const Ray& ray, F4& normal, Stats* stats) {
+    // src/ThreadedShader.cpp:15-19
+    if (s.useBVH && s.numBoxes > 0) return BVHTraverse(s, ray, normal, stats);
+    return LinearTraverse(s, ray, normal, stats);
+}
+
+// ---------------------------------------------------------------------------
+// src/Shading.h
+// ---------------------------------------------------------------------------
+namespace Shading {
+
+// :15-18
+inline float SchlickFresnel(float value) {
+    float temp = 1.0f - value;
+    return temp * temp * temp * temp * temp;
+}
+// :20-24
+inline F4 Tint(F4 albedo) {
+    float luminance = albedo.x * 0.3f + albedo.y * 0.6f + albedo.z;
+    float condition = luminance > 0.0f;
+    return lerp_c(WHITE, mul(albedo, 1.0f / luminance), condition);
+}
+// :26-30
+inline F4 Sheen(float cosLightHalf, const RtxMaterial& m) {
+    F4 tint = Tint(from(m.albedo));
+    F4 sheen = lerp_c(WHITE, tint, m.tintRoughness);
+    return mul(mul(sheen, SchlickFresnel(cosLightHalf)), m.sheen);
+}
+// :32-41 — ONE_OVER_PI expands to 1.0f/3.1415926535f (unparenthesised)
+inline float DiffuseBRDF(float cosView, float cosLight, const RtxMaterial& m) {
+    float FL = SchlickFresnel(cosLight);
+    float FV = SchlickFresnel(cosView);
+    float R = 0.5f + 2.0f * cosLight * cosLight * m.roughness * m.roughness;
+    float retro = R * (FL + FV + FL * FV * (R - 1.0f));
+    return 1.0f / PI_F * ((1.0f - 0.5f * FL) * (1.0f - 0.5f * FV) + retro);
+}
+// :43-54 — cos() is the double overload; product formed in double
+inline float GgxAnisotropic(F4 h, float ax, float ay) {
+    float dotHX2 = h.x * h.x;
+    float dotHY2 = h.z * h.z;
+    float cos2Theta = (float)(cos((double)h.y) * cos((double)h.y));
+    float ax2 = ax * ax;
+    float ay2 = ay * ay;
+    float temp = (dotHX2 / ax2 + dotHY2 / ay2 + cos2Theta);
+    return 1.0f / PI_F * 1.0f / (ax * ay * temp * temp);
+}
+// :56-72 — sqrt() is the double overload
+inline float SeparableSmithGGXG1BSDF(F4 vector, F4 h, float ax, float ay) {
+    float cos2Theta = h.y * h.y;
+    float sin2Theta = 1.0f - cos2Theta;
+    float tanTheta = (float)sqrt((double)(sin2Theta / cos2Theta));
+    float cos2Phi = vector.x * vector.x;
+    float sin2Phi = 1.0f - cos2Phi;
+    float a = (float)sqrt((double)(cos2Phi * ax * ax + sin2Phi * ay * ay));
+    float a2Tan2Theta = a * a * tanTheta * tanTheta;
+    float lambda = (float)(0.5f * (-1.0f + sqrt((double)(1.0f + a2Tan2Theta))));
+    return 1.0f / (1.0f + lambda);
+}
+inline void AxAy(const RtxMaterial& m, float& ax, float& ay) {
+    // :76-81 == :94-99 — fmax is the double overload, values are floats
+    float aspect = (float)sqrt((double)(1.0f - 0.9f * m.anisotropy));
+    float roughnessSqr = m.roughness * m.roughness;
+    ax = (float)fmax(0.001f, roughnessSqr / aspect);
+    ay = (float)fmax(0.001f, roughnessSqr * aspect);
+}
+// :74-91
+inline float SpecularBSDF(F4 normal, F4 l, F4 v, F4 h, const RtxMaterial& m) {
+    float ax, ay; AxAy(m, ax, ay);
+    float cosLight = dot(normal, l);
+    float cosView = dot(normal, v);
+    float D = GgxAnisotropic(h, ax, ay);
+    float Gl = SeparableSmithGGXG1BSDF(l, h, ax, ay);
+    float Gv = SeparableSmithGGXG1BSDF(v, h, ax, ay);
+    return D * Gl * Gv / (4.0f * cosLight * cosView);
+}
+// :93-115
+inline F4 SpecularTransmissionBSDF(F4 l, F4 v, F4 h, const RtxMaterial& m) {
+    float ax, ay; AxAy(m, ax, ay);
+    float cosViewHalf = dot(v, h);
+    cosViewHalf *= h.y;
+    float eta = 1.0f / m.indexOfRefraction;
+    float D = GgxAnisotropic(h, ax, ay);
+    float Gl = SeparableSmithGGXG1BSDF(l, h, ax, ay);
+    float Gv = SeparableSmithGGXG1BSDF(v, h, ax, ay);
+    float F = eta + (1.0f - eta) * SchlickFresnel(cosViewHalf);
+    float result = D * F * Gl * Gv;
+    return F4{result, result, result, result};
+}
+// :117-126 — log2() is the double overload; the quotient is formed in double
+inline float GTR(float cosLightHalf, float alpha) {
+    if (alpha >= 1.0f) return 1.0f / PI_F;
+    float alphaSqr = alpha * alpha;
+    float decAlphaSqr = alphaSqr - 1.0f;
+    return (float)(1.0f / PI_F * decAlphaSqr / (log2((double)alphaSqr) * (1.0f + decAlphaSqr * cosLightHalf * cosLightHalf)));
+}
+// :128-131 — sqrt() double; "1 - a2" int literal
+inline float SeparableSmithGGXG1(float cosine, float alpha) {
+    float a2 = alpha * alpha;
+    return (float)(2.0f / (1.0f + sqrt((double)(a2 + (1 - a2) * cosine * cosine))));
+}
+// :133-150
+inline F4 ClearcoatBRDF(F4 v, F4 l, F4 h, const RtxMaterial& m) {
+    float cosHalf = (float)fabs(h.y);
+    float cosView = (float)fabs(v.y);
+    float cosLight = (float)fabs(l.y);
+    float cosLightHalf = dot(l, h);
+    float scale = 0.1f + (0.001f - 0.1f) * m.clearcoatRoughness;
+    float D = GTR(cosHalf, scale);
+    float Gl = SeparableSmithGGXG1(cosLight, 0.25f);
+    float Gv = SeparableSmithGGXG1(cosView, 0.25f);
+    float F = 0.04f + 0.96f * SchlickFresnel(cosLightHalf);
+    float result = 0.25f * D * Gl * Gv * F;
+    return F4{result, result, result, result};
+}
+
+// texel fetch with the UB-only deviations described in the file header
+inline uint32_t Texel(const Scene& s, int64_t index) {
+    const int64_t pad = 8192 + 2;   // tail padding the device backend also allocates
+    if (index < 0) index = 0;
+    if (index >= (int64_t)s.numTexels + pad) index = (int64_t)s.numTexels + pad - 1;
+    return index < (int64_t)s.numTexels ? s.textureData[index] : 0u;
+}
+inline int ToInt(float v) { return (v != v || v >= 2147483648.0f || v < -2147483648.0f) ? INT32_MIN : (int)v; }
+
+// :152-155
+inline F4 Unpack(uint32_t color) {
+    unsigned char byte[4]; memcpy(byte, &color, 4);
+    return mul(F4{(float)byte[0], (float)byte[1], (float)byte[2], (float)byte[3]}, ONE_OVER_UCHAR_MAX);
+}
+// :157-182 — floor() double; taps are not clamped
+inline F4 BilinearFilter(const Scene& s, float u, float v, int width, int height, int offset) {
+    float texCoord[2] = {u * (width - 1), v * (height - 1)};
+    float texel[2] = {(float)floor((double)texCoord[0]), (float)floor((double)texCoord[1])};
+    float frac[2] = {texCoord[0] - texel[0], texCoord[1] - texel[1]};
+    int64_t tx = ToInt(texel[0]), ty = ToInt(texel[1]);
+    // the reference's index arithmetic is 32-bit int
+    int32_t i00 = (int32_t)((uint32_t)offset + (uint32_t)((int32_t)ty * width) + (uint32_t)(int32_t)tx);
+    int32_t i01 = (int32_t)((uint32_t)offset + (uint32_t)(((int32_t)ty + 1) * width) + (uint32_t)(int32_t)tx);
+    F4 c00 = Unpack(Texel(s, i00));
+    F4 c10 = Unpack(Texel(s, (int64_t)(int32_t)((uint32_t)i00 + 1u)));
+    F4 c01 = Unpack(Texel(s, i01));
+    F4 c11 = Unpack(Texel(s, (int64_t)(int32_t)((uint32_t)i01 + 1u)));
+    F4 color = add(add(add(mul(mul(c00, (1.0f - frac[0])), (1.0f - frac[1])),
+                           mul(mul(c10, frac[0]), (1.0f - frac[1]))),
+                       mul(mul(c01, (1.0f - frac[0])), frac[1])),
+                   mul(mul(c11, frac[0]), frac[1]));
+    return color;
+}
+// :184-193 — offset travels through a `const float&`
+inline F4 ColorSample(const Scene& s, float u, float v, int width, int height, float offset) {
+    return BilinearFilter(s, u, v, width, height, (int)offset);
+}
+// :195-232
+inline F4 GetTexturePixel(const Scene& s, const RtxObject& o, const RtxTexture& info, F4 p, F4 normal) {
+    F4 texCoord = f4(0, 0, 0);
+    if (o.type == RTX_SPHERE) {
+        float theta = (float)(atan2((double)normal.z, (double)normal.x) + PI_F);
+        float phi = (float)acos((double)normal.y);
+        texCoord.x = theta;
+        texCoord.y = phi;
+        texCoord = divs(mul(texCoord, 1.0f), PI_F);      // texCoord * 1.0f / 3.1415926535f
+    } else if (o.type == RTX_TRIANGLE) {
+        F4 A = from(o.vertices[0]), B = from(o.vertices[1]), C = from(o.vertices[2]);
+        float area = ((B.x - A.x) * (C.y - A.y) - (B.y - A.y) * (C.x - A.x)) * 0.5f;
+        float areaPBC = ((B.x - p.x) * (C.y - p.y) - (B.y - p.y) * (C.x - p.x)) * 0.5f;
+        float areaPCA = ((C.x - p.x) * (A.y - p.y) - (C.y - p.y) * (A.x - p.x)) * 0.5f;
+        texCoord.x = areaPBC / area;
+        texCoord.y = areaPCA / area;
+        texCoord.z = 1.0f - texCoord.x - texCoord.y;
+        texCoord = clamp01_sse(texCoord);
+    }
+    return ColorSample(s, texCoord.x, texCoord.y, info.width, info.height, (float)info.offset);
+}
+
+} // namespace Shading
+
+// src/ThreadedShader.cpp:37-43
+inline F4 DiffuseReflect(F4 normal, uint32_t& seed) {
+    F4 randomDirection = RandomDirection(seed);
+    float cosDirection = dot(normal, randomDirection);
+    return normalize(add(mul(randomDirection, cosDirection), normal));
+}
+// :45-48
+inline F4 Reflect(F4 incident, F4 normal) {
+    return normalize(sub(incident, mul(normal, (2.0f * dot(incident, normal)))));
+}
+// :50-65 — sqrt() double overload of a float, result stored to float
+inline F4 Refract(F4 incident, F4 normal, float n1, float n2) {
+    float cosI = -dot(incident, normal);
+    float sinR2 = (1.0f - cosI * cosI);
+    float eta = n1 / n2;
+    if (eta * sinR2 > 1.0f) return f4(0, 0, 0);
+    float cosR2 = (float)sqrt((double)(1.0f - sinR2 * sinR2));
+    F4 direction = add(mul(incident, eta), mul(normal, (eta * cosI - cosR2)));
+    return normalize(direction);
+}
+// :67-80
+inline F4 CalculateWeights(float metallicC, float transparencyC, const RtxMaterial& m) {
+    float metallic = metallicC;
+    float transmission = (1.0f - metallicC) * transparencyC;
+    float dielectric = (1.0f - metallicC) * (1.0f - transparencyC);
+    F4 w = F4{metallic + dielectric, transmission, dielectric, m.clearcoatThickness};
+    return normalize(w);
+}
+
+// src/ThreadedShader.cpp:82-132. Vector3::Lerp clamps material.metallic /
+// material.transparency IN PLACE through a non-const reference
+// (src/Vector3.h:49-52), and every later read of them in this function comes
+// after those calls, so both are clamped once on entry.
+F4 ComputeColor(const Scene& s, const RtxCamera& cam, Ray& ray, const Sample& sample, F4& lightSample, uint32_t& seed, F4 normal) {
+    const RtxObject& object = s.objects[sample.objectID];
+    const RtxMaterial& material = s.materials[object.materialID];
+    const RtxTexture& info = s.textureInfo[material.textureID];
+
+    F4 lightVector = normalize(mul(ray.direction, -1.0f));
+    F4 viewVector = normalize(sub(from(cam.position), sample.point));
+    F4 halfVector = normalize(add(lightVector, viewVector));
+
+    F4 diffusionDirection = DiffuseReflect(normal, seed);
+    F4 reflectionDirection = Reflect(ray.direction, normal);
+    F4 refractionDirection = Refract(viewVector, normal, 1.0f, material.indexOfRefraction);
+
+    float metallic = clamp01_libm(material.metallic);
+    F4 outgoing = lerp_v(diffusionDirection, reflectionDirection, metallic);
+
+    float transparency = clamp01_libm(material.transparency);
+    ray.origin = sample.point;
+    ray.direction = normalize(lerp_v(outgoing, refractionDirection, transparency));
+
+    float cosLight = (float)fmax(1e-6f, dot(normal, lightVector));
+    float cosView = (float)fmax(1e-6f, dot(normal, viewVector));
+    float cosLightHalf = (float)fmax(1e-6f, dot(lightVector, halfVector));
+
+    F4 emission = mul(from(material.albedo), material.emmissionIntensity);
+    float isEmissive = (emission.x + emission.y + emission.z) > 0.0f;
+
+    F4 texture = Shading::GetTexturePixel(s, object, info, sample.point, normal);
+
+    F4 diffuseAlbedo = mul(mul(texture, from(material.tint)), (1.0f - metallic));
+    F4 specularAlbedo = lerp_c(from(material.specular), WHITE, metallic);
+    float fresnel = Shading::SchlickFresnel(cosLightHalf);
+
+    F4 diffuseComponent = mul(mul(diffuseAlbedo, (1.0f - fresnel)), Shading::DiffuseBRDF(cosView, cosLight, material));
+    F4 specularComponent = mul(mul(specularAlbedo, fresnel), Shading::SpecularBSDF(normal, lightVector, viewVector, halfVector, material));
+    F4 transmissionComponent = Shading::SpecularTransmissionBSDF(lightVector, viewVector, halfVector, material);
+    F4 clearcoatComponent = Shading::ClearcoatBRDF(viewVector, lightVector, halfVector, material);
+    F4 sheenComponent = Shading::Sheen(cosLightHalf, material);
+
+    F4 weights = CalculateWeights(metallic, transparency, material);
+
+    F4 colorSample = mul(emission, isEmissive);
+    colorSample = add(colorSample, mul(add(diffuseComponent, sheenComponent), weights.z));
+    colorSample = add(colorSample, mul(clearcoatComponent, weights.w));
+    colorSample = add(colorSample, mul(specularComponent, weights.x));
+    colorSample = add(colorSample, mul(transmissionComponent, weights.y));
+    colorSample = mul(mul(colorSample, lightSample), (float)(cosLight > 0.0f));
+
+    lightSample = mul(mul(mul(mul(lightSample, texture), from(material.albedo)), 2.0f), cosLight);
+    return colorSample;
+}
+
+// src/ThreadedShader.cpp:160-171 — atan2/acos double; "* ONE_OVER_PI" is
+// "* 1.0f / 3.1415926535f" evaluated in double
+inline F4 SkyTexel(const Scene& s, const Ray& ray) {
+    const RtxTexture& info = s.textureInfo[1];
+    float u = (float)((atan2((double)ray.direction.x, (double)ray.direction.z) + PI_F) * 1.0f / PI_F);
+    float v = (float)(acos((double)(-ray.direction.y)) * 1.0f / PI_F);
+    return Shading::ColorSample(s, u, v, info.width, info.height, (float)info.offset);
+}
+
+struct PathOut { F4 accumulator; int rays; int hits[4]; int firstID; };
+
+// src/ThreadedShader.cpp:141-177 — one pixel, up to 4 bounces
+PathOut TracePixel(const Scene& s, const RtxCamera& cam, uint32_t fc, int x, int y, Stats* stats) {
+    PathOut out{}; out.firstID = -1;
+    uint32_t seed;
+    Ray ray = PrimaryRay(s, cam, fc, x, y, seed);
+    F4 accumulator = F4{0, 0, 0, 0};
+    F4 lightSample = WHITE;
+    for (int iter = 0; iter < 4; iter++) {
+        F4 normal = f4(0, 0, 0);
+        Sample sample = Traverse(s, ray, normal, stats);
+        out.rays++;
+        if (iter == 0) out.firstID = sample.objectID;
+        if (sample.objectID < 0) {
+            F4 texel = SkyTexel(s, ray);
+            accumulator = add(accumulator, mul(texel, lightSample));
+            break;
+        }
+        out.hits[iter]++;
+        F4 colorSample = ComputeColor(s, cam, ray, sample, lightSample, seed, normal);
+        lightSample = clamp01_sse(lightSample);
+        accumulator = clamp01_sse(add(accumulator, colorSample));
+    }
+    out.accumulator = accumulator;
+    return out;
+}
+
+Scene make_scene(const RtxSceneDesc* d) {
+    Scene s;
+    s.objects = d->objects; s.numObjects = d->numObjects;
+    s.materials = d->materials; s.numMaterials = d->numMaterials;
+    s.boxes = d->boxes; s.numBoxes = d->numBoxes;
+    s.textureInfo = d->textureInfo; s.numTextures = d->numTextures;
+    s.textureData = d->textureData; s.numTexels = d->numTexels;
+    s.width = d->width; s.height = d->height; s.useBVH = d->useBVH;
+    return s;
+}
+
+template <class Fn>
+void parallel_rows(int y0, int y1, int nthreads, Fn fn) {
+    // dynamic row hand-out (the reference uses static bands,
+    // src/ThreadedShader.cpp:186-207; pixels are independent, so the result
+    // does not depend on the split)
+    if (nthreads <= 1) { for (int y = y0; y < y1; ++y) fn(y); return; }
+    std::atomic<int> next(y0);
+    std::vector<std::thread> ts;
+    for (int t = 0; t < nthreads; ++t)
+        ts.emplace_back([&]() { for (;;) { int y = next.fetch_add(1); if (y >= y1) break; fn(y); } });
+    for (auto& t : ts) t.join();
+}
+
+} // namespace
+
+extern "C" {
+
+typedef struct OrcStats {
+    uint64_t rays; uint64_t raysPerBounce[4]; uint64_t hitsPerBounce[4];
+    uint64_t innerVisits; uint64_t leafTests;
+} OrcStats;
+
+// ThreadedShader::Render over rows [y0,y1): pixels (w*h*4 floats) is the
+// running mean, updated in place (src/ThreadedShader.cpp:179-180).
+// collectStats: 0 none, 1 rays/hits only, 2 also node/leaf visit counts.
+int orc_render_rows(const RtxSceneDesc* d, const RtxCamera* cam, uint32_t fc, float* pixels,
+                    int y0, int y1, int nthreads, int collectStats, OrcStats* statsOut) {
+    Scene s = make_scene(d);
+    if (y0 < 0) y0 = 0; if (y1 > (int)s.height) y1 = (int)s.height;
+    std::vector<OrcStats> rowStats(collectStats ? (size_t)(y1 > y0 ? y1 - y0 : 0) : 0);
+    parallel_rows(y0, y1, nthreads, [&](int y) {
+        OrcStats rs{}; Stats st{0, 0};
+        for (int x = 0; x < (int)s.width; ++x) {
+            PathOut po = TracePixel(s, *cam, fc, x, y, collectStats >= 2 ? &st : nullptr);
+            uint32_t index = (uint32_t)(y * (int)s.width + x);
+            float scale = 1.0f / (fc + 1);
+            F4 prev = F4{pixels[4 * (size_t)index], pixels[4 * (size_t)index + 1], pixels[4 * (size_t)index + 2], pixels[4 * (size_t)index + 3]};
+            F4 res = lerp_c(prev, po.accumulator, scale);
+            pixels[4 * (size_t)index] = res.x; pixels[4 * (size_t)index + 1] = res.y;
+            pixels[4 * (size_t)index + 2] = res.z; pixels[4 * (size_t)index + 3] = res.w;
+            if (collectStats) {
+                rs.rays += po.rays;
+                int alive = 1;
+                for (int b = 0; b < 4; ++b) { if (b < po.rays) rs.raysPerBounce[b]++; rs.hitsPerBounce[b] += po.hits[b]; }
+                (void)alive;
+            }
+        }
+        if (collectStats) { rs.innerVisits = st.inner; rs.leafTests = st.leaf; rowStats[y - y0] = rs; }
+    });
+    if (collectStats && statsOut) {
+        OrcStats t{};
+        for (auto& r : rowStats) {
+            t.rays += r.rays; t.innerVisits += r.innerVisits; t.leafTests += r.leafTests;
+            for (int b = 0; b < 4; ++b) { t.raysPerBounce[b] += r.raysPerBounce[b]; t.hitsPerBounce[b] += r.hitsPerBounce[b]; }
+        }
+        *statsOut = t;
+    }
+    return 0;
+}
+
+int orc_render(const RtxSceneDesc* d, const RtxCamera* cam, uint32_t fc, float* pixels, int nthreads) {
+    return orc_render_rows(d, cam, fc, pixels, 0, (int)d->height, nthreads, 0, nullptr);
+}
+
+// sample.objectID of the first traverse() per pixel (frame fc); mode: 0 = as
+// configured by useBVH, 1 = force BVHTraverse, 2 = force LinearTraverse.
+int orc_primary_hits(const RtxSceneDesc* d, const RtxCamera* cam, uint32_t fc, int32_t* ids, int mode, int nthreads) {
+    Scene s = make_scene(d);
+    if (mode == 1) s.useBVH = 1;
+    if (mode == 2) s.useBVH = 0;
+    parallel_rows(0, (int)s.height, nthreads, [&](int y) {
+        for (int x = 0; x < (int)s.width; ++x) {
+            uint32_t seed; F4 n = f4(0, 0, 0);
+            Ray ray = PrimaryRay(s, *cam, fc, x, y, seed);
+            ids[(size_t)y * s.width + x] = Traverse(s, ray, n, nullptr).objectID;
+        }
+    });
+    return 0;
+}
+
+// primary rays themselves (origin xyz0, direction xyz0), for kernel unit tests
+int orc_primary_rays(const RtxSceneDesc* d, const RtxCamera* cam, uint32_t fc, float* origins, float* directions) {
+    Scene s = make_scene(d);
+    for (int y = 0; y < (int)s.height; ++y)
+        for (int x = 0; x < (int)s.width; ++x) {
+            uint32_t seed; Ray ray = PrimaryRay(s, *cam, fc, x, y, seed);
+            size_t i = ((size_t)y * s.width + x) * 4;
+            origins[i] = ray.origin.x; origins[i + 1] = ray.origin.y; origins[i + 2] = ray.origin.z; origins[i + 3] = 0;
+            directions[i] = ray.direction.x; directions[i + 1] = ray.direction.y; directions[i + 2] = ray.direction.z; directions[i + 3] = 0;
+        }
+    return 0;
+}
+
+// traverse() on caller-supplied rays
+int orc_trace_rays(const RtxSceneDesc* d, const float* origins, const float* directions, uint64_t n,
+                   int32_t* ids, float* points, float* normals, int mode, int nthreads, uint64_t* innerOut, uint64_t* leafOut) {
+    Scene s = make_scene(d);
+    if (mode == 1) s.useBVH = 1;
+    if (mode == 2) s.useBVH = 0;
+    const int chunk = 4096;
+    int nchunks = (int)((n + chunk - 1) / chunk);
+    std::vector<Stats> cs((size_t)nchunks, Stats{0, 0});
+    parallel_rows(0, nchunks, nthreads, [&](int c) {
+        uint64_t b = (uint64_t)c * chunk, e = b + chunk < n ? b + chunk : n;
+        for (uint64_t i = b; i < e; ++i) {
+            Ray ray; ray.origin = f4(origins[4 * i], origins[4 * i + 1], origins[4 * i + 2]);
+            ray.direction = f4(directions[4 * i], directions[4 * i + 1], directions[4 * i + 2]);
+            F4 nrm = f4(0, 0, 0);
+            Sample sm = Traverse(s, ray, nrm, (innerOut || leafOut) ? &cs[c] : nullptr);
+            if (ids) ids[i] = sm.objectID;
+            if (points) { points[4 * i] = sm.point.x; points[4 * i + 1] = sm.point.y; points[4 * i + 2] = sm.point.z; points[4 * i + 3] = sm.point.w; }
+            if (normals) { normals[4 * i] = nrm.x; normals[4 * i + 1] = nrm.y; normals[4 * i + 2] = nrm.z; normals[4 * i + 3] = nrm.w; }
+        }
+    });
+    uint64_t in = 0, lf = 0; for (auto& c : cs) { in += c.inner; lf += c.leaf; }
+    if (innerOut) *innerOut = in; if (leafOut) *leafOut = lf;
+    return 0;
+}
+
+// ---- piecewise entry points (checked against oracle/_ref/libref_parts.so) ----
+float orc_rand(uint32_t* seed) { return Rand(*seed); }
+void orc_random_direction(uint32_t* seed, float* out3) { F4 d = RandomDirection(*seed); out3[0] = d.x; out3[1] = d.y; out3[2] = d.z; }
+void orc_pixel_position(const RtxCamera* cam, int x, int y, int w, int h, float* out4) {
+    F4 p = CalculatePixelPosition(*cam, x, y, w, h); out4[0] = p.x; out4[1] = p.y; out4[2] = p.z; out4[3] = p.w;
+}
+// out[0]=SchlickFresnel(c[0]) out[1]=DiffuseBRDF(cosView=c[0],cosLight=c[1]) out[2]=SpecularBSDF
+// out[3]=SpecularTransmissionBSDF.R out[4]=ClearcoatBRDF.R out[5..8]=Sheen(c[2]) rgba
+void orc_shading_terms(const RtxMaterial* m, const float* n3, const float* l3, const float* v3, const float* h3, const float* c3, float* out9) {
+    F4 n = f4(n3[0], n3[1], n3[2]), l = f4(l3[0], l3[1], l3[2]), v = f4(v3[0], v3[1], v3[2]), h = f4(h3[0], h3[1], h3[2]);
+    out9[0] = Shading::SchlickFresnel(c3[0]);
+    out9[1] = Shading::DiffuseBRDF(c3[0], c3[1], *m);
+    out9[2] = Shading::SpecularBSDF(n, l, v, h, *m);
+    out9[3] = Shading::SpecularTransmissionBSDF(l, v, h, *m).x;
+    out9[4] = Shading::ClearcoatBRDF(v, l, h, *m).x;
+    F4 sh = Shading::Sheen(c3[2], *m);
+    out9[5] = sh.x; out9[6] = sh.y; out9[7] = sh.z; out9[8] = sh.w;
+}
+void orc_get_texture_pixel(const RtxSceneDesc* d, const RtxObject* o, const RtxTexture* info, const float* p3, const float* n3, float* out4) {
+    Scene s = make_scene(d);
+    F4 c = Shading::GetTexturePixel(s, *o, *info, f4(p3[0], p3[1], p3[2]), f4(n3[0], n3[1], n3[2]));
+    out4[0] = c.x; out4[1] = c.y; out4[2] = c.z; out4[3] = c.w;
+}
+void orc_color_sample(const RtxSceneDesc* d, float u, float v, const RtxTexture* info, float* out4) {
+    Scene s = make_scene(d);
+    F4 c = Shading::ColorSample(s, u, v, info->width, info->height, (float)info->offset);
+    out4[0] = c.x; out4[1] = c.y; out4[2] = c.z; out4[3] = c.w;
+}
+
+} // extern "C"
