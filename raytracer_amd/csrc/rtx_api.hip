@@ -1,0 +1,600 @@
+// rtx_api.hip — host side of the C-ABI in include/rtx.h: validation, AoS -> SoA
+// flattening of the reference's boxes/objects, device residency, and the
+// per-frame launch sequence. No torch types, no CPU rendering fallback: every
+// entry point that computes anything launches HIP kernels or fails.
+#include "../../include/rtx.h"
+#include "rtx_kernels.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+static thread_local std::string g_err;
+static int fail(const std::string& m) { g_err = m; return 1; }
+
+#define HIP_TRY(expr)                                                                        \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess) return fail(std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+static const int kRing = 4;       // frames whose timing events may still be pending
+static const int kEvents = 10;    // start + one per kernel (8) + end
+
+struct RtxRenderer {
+    RtxConfig cfg{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int numCUs = 256;
+    uint32_t width = 0, height = 0;
+    int mode = RTX_MODE_CULLED;
+    bool linear = false;
+
+    DevScene sc{};
+    // device allocations
+    float4 *dInner = nullptr, *dLeaf = nullptr, *dShade = nullptr, *dMaterials = nullptr;
+    int4* dTexInfo = nullptr;
+    uint32_t* dTexels = nullptr;
+    int2* dTiles = nullptr;
+    float4 *dRqO[2] = {nullptr, nullptr}, *dRqD[2] = {nullptr, nullptr};
+    float* dHitT = nullptr; int* dHitLeaf = nullptr;
+    float4 *dLight = nullptr, *dAcc = nullptr, *dFb = nullptr;
+    uint32_t *dSeeds = nullptr, *dCtrl = nullptr;
+    unsigned long long* dStats = nullptr;
+
+    // tiles
+    int tileW = 64, tileH = 32, tilesX = 0, tilesY = 0;
+    std::vector<int2> localTiles;
+    std::vector<std::vector<int2>> tilesOfRank;   // for unpack
+    std::vector<int2*> dTilesOfRank;
+    uint64_t localPixels = 0;
+    uint32_t numSlots = 0;
+
+    // launch geometry
+    int gridTrace = 0, gridShade = 0;
+    size_t ldsTrace = 0;
+
+    // timing
+    hipEvent_t ev[kRing][kEvents];
+    bool pending[kRing] = {false, false, false, false};
+    int ringPos = 0;
+    RtxCounters totals{};
+    std::vector<float> hostStage;   // D2H staging for worldSize > 1
+};
+
+// ---------------------------------------------------------------------------------
+// validation + flatten
+// ---------------------------------------------------------------------------------
+namespace {
+
+struct Flat {
+    std::vector<float4> inner, leaf, shade;
+    int rootRef = 0;
+    int maxDepth = 0;
+};
+
+inline float i2f(int32_t v) { float f; memcpy(&f, &v, 4); return f; }
+
+void emit_leaf(const RtxObject& o, int32_t objectID, int32_t boxID, Flat& f) {
+    const RtxVec4 A = o.vertices[0], B = o.vertices[1], C = o.vertices[2];
+    float4 q0, q1, q2, q3;
+    if (o.type == RTX_TRIANGLE) {
+        // e1 = B - A, e2 = C - A: the same two subtractions the reference performs
+        // first in IntersectTriangle (src/ThreadedShader.cpp:298-299)
+        const float e1x = B.x - A.x, e1y = B.y - A.y, e1z = B.z - A.z;
+        const float e2x = C.x - A.x, e2y = C.y - A.y, e2z = C.z - A.z;
+        q0 = make_float4(A.x, A.y, A.z, e1x);
+        q1 = make_float4(e1y, e1z, e2x, e2y);
+        q2 = make_float4(e2z, i2f(objectID), i2f(boxID), i2f(o.type));
+        q3 = make_float4(B.x, B.y, C.x, C.y);
+    } else {
+        q0 = make_float4(o.position.x, o.position.y, o.position.z, o.radius);
+        q1 = make_float4(0, 0, 0, 0);
+        q2 = make_float4(0, i2f(objectID), i2f(boxID), i2f(o.type));
+        q3 = make_float4(0, 0, 0, 0);
+    }
+    f.leaf.push_back(q0); f.leaf.push_back(q1); f.leaf.push_back(q2); f.leaf.push_back(q3);
+    const RtxVec4 n0 = o.normals[0], n1 = o.normals[1], n2 = o.normals[2];
+    f.shade.push_back(make_float4(n0.x, n0.y, n0.z, n1.x));
+    f.shade.push_back(make_float4(n1.y, n1.z, n2.x, n2.y));
+    f.shade.push_back(make_float4(n2.z, i2f(o.materialID), 0, 0));
+}
+
+const int32_t kNoChild = (int32_t)0x80000000;   // never passes (see traverse_bvh)
+
+int flatten(const RtxSceneDesc& s, bool useBVH, Flat& f) {
+    const uint64_t nObj = s.numObjects, nBox = s.numBoxes;
+    for (uint64_t i = 0; i < nObj; ++i) {
+        const int32_t m = s.objects[i].materialID;
+        if (m < 0 || (uint64_t)m >= s.numMaterials) return fail("object " + std::to_string(i) + ": materialID out of range");
+    }
+    if (!useBVH) {
+        f.leaf.reserve(nObj * 4); f.shade.reserve(nObj * 3);
+        for (uint64_t i = 0; i < nObj; ++i) emit_leaf(s.objects[i], (int32_t)i, (int32_t)i, f);
+        f.rootRef = 0; f.maxDepth = 0;
+        return 0;
+    }
+    if (nBox > 0x7fffffffull) return fail("too many boxes");
+    // index of every box inside its own array (inner / leaf), in box order
+    std::vector<int32_t> slotOf(nBox);
+    int32_t nInner = 0, nLeaf = 0;
+    for (uint64_t b = 0; b < nBox; ++b) {
+        const RtxBoundingBox& box = s.boxes[b];
+        if (box.objectID != -1) {
+            if (box.objectID < 0 || (uint64_t)box.objectID >= nObj) return fail("box " + std::to_string(b) + ": objectID out of range");
+            slotOf[b] = nLeaf++;
+        } else {
+            slotOf[b] = nInner++;
+        }
+    }
+    f.inner.assign((size_t)nInner * 4, make_float4(0, 0, 0, 0));
+    f.leaf.reserve((size_t)nLeaf * 4); f.shade.reserve((size_t)nLeaf * 3);
+    for (uint64_t b = 0; b < nBox; ++b) {
+        const RtxBoundingBox& box = s.boxes[b];
+        if (box.objectID != -1) { emit_leaf(s.objects[box.objectID], box.objectID, (int32_t)b, f); continue; }
+        float lo[2][3] = {{0, 0, 0}, {0, 0, 0}}, hi[2][3] = {{0, 0, 0}, {0, 0, 0}};
+        int32_t ref[2] = {kNoChild, kNoChild};
+        const int32_t child[2] = {box.leftID, box.rightID};
+        for (int k = 0; k < 2; ++k) {
+            if (child[k] == -1) continue;     // the reference guards children with != -1 (src/ThreadedShader.cpp:380,387)
+            if (child[k] < 0 || (uint64_t)child[k] >= nBox) return fail("box " + std::to_string(b) + ": child out of range");
+            const RtxBoundingBox& c = s.boxes[child[k]];
+            lo[k][0] = c.minimalPosition.x; lo[k][1] = c.minimalPosition.y; lo[k][2] = c.minimalPosition.z;
+            hi[k][0] = c.maximalPosition.x; hi[k][1] = c.maximalPosition.y; hi[k][2] = c.maximalPosition.z;
+            ref[k] = c.objectID != -1 ? ~slotOf[child[k]] : slotOf[child[k]];
+        }
+        float4* n = &f.inner[(size_t)slotOf[b] * 4];
+        n[0] = make_float4(lo[0][0], lo[0][1], lo[0][2], hi[0][0]);
+        n[1] = make_float4(hi[0][1], hi[0][2], lo[1][0], lo[1][1]);
+        n[2] = make_float4(lo[1][2], hi[1][0], hi[1][1], hi[1][2]);
+        n[3] = make_float4(i2f(ref[0]), i2f(ref[1]), 0, 0);
+    }
+    f.rootRef = s.boxes[0].objectID != -1 ? ~slotOf[0] : slotOf[0];
+    // depth + tree check: every box may be reached at most once from the root
+    std::vector<uint8_t> seen(nBox, 0);
+    std::vector<std::pair<int32_t, int32_t>> st;
+    st.emplace_back(0, 0);
+    int maxDepth = 0;
+    while (!st.empty()) {
+        auto [b, depth] = st.back(); st.pop_back();
+        if (seen[b]) return fail("boxes do not form a tree (box " + std::to_string(b) + " reached twice)");
+        seen[b] = 1;
+        maxDepth = std::max(maxDepth, depth);
+        const RtxBoundingBox& box = s.boxes[b];
+        if (box.objectID != -1) continue;
+        if (box.leftID != -1) st.emplace_back(box.leftID, depth + 1);
+        if (box.rightID != -1) st.emplace_back(box.rightID, depth + 1);
+    }
+    f.maxDepth = maxDepth;
+    return 0;
+}
+
+template <class T>
+int upload(T** dst, const void* src, size_t bytes, size_t allocBytes = 0) {
+    if (allocBytes < bytes) allocBytes = bytes;
+    if (allocBytes == 0) allocBytes = 64;
+    HIP_TRY(hipMalloc((void**)dst, allocBytes));
+    if (allocBytes > bytes) HIP_TRY(hipMemset((char*)*dst + bytes, 0, allocBytes - bytes));
+    if (bytes) HIP_TRY(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
+    return 0;
+}
+
+DevFrame make_frame(const RtxRenderer* r, const RtxCamera* cam, uint32_t fc) {
+    DevFrame fr{};
+    fr.front[0] = cam->front.x; fr.front[1] = cam->front.y; fr.front[2] = cam->front.z;
+    fr.up[0] = cam->up.x; fr.up[1] = cam->up.y; fr.up[2] = cam->up.z;
+    fr.right[0] = cam->right.x; fr.right[1] = cam->right.y; fr.right[2] = cam->right.z;
+    fr.pos[0] = cam->position.x; fr.pos[1] = cam->position.y; fr.pos[2] = cam->position.z; fr.pos[3] = cam->position.w;
+    fr.aspect = cam->aspectRatio; fr.nearView = cam->nearView;
+    // src/Camera.h:58 — tan() is the double overload of a float product; a per-frame constant
+    fr.tanHalfFOV = (float)tan((double)(0.0174532925f * cam->fov * 0.5f));
+    fr.frameCounter = fc;
+    fr.lerpScale = 1.0f / (float)(fc + 1u);   // uint32 arithmetic, then float (src/ThreadedShader.cpp:179)
+    fr.width = (int)r->width; fr.height = (int)r->height;
+    fr.tileW = r->tileW; fr.tileH = r->tileH; fr.tilesX = r->tilesX;
+    fr.numLocalTiles = (int)r->localTiles.size();
+    fr.numSlots = (int)r->numSlots;
+    return fr;
+}
+
+void finish_timing(RtxRenderer* r, int slot) {
+    if (!r->pending[slot]) return;
+    hipEventSynchronize(r->ev[slot][kEvents - 1]);
+    float total = 0, trace = 0, shade = 0, ms = 0;
+    hipEventElapsedTime(&total, r->ev[slot][0], r->ev[slot][kEvents - 1]);
+    // kernel k (0..7) runs between events k and k+1: even = trace (primary, trace), odd = shade
+    for (int k = 0; k < 8; ++k) {
+        hipEventElapsedTime(&ms, r->ev[slot][k], r->ev[slot][k + 1]);
+        if (k & 1) shade += ms; else trace += ms;
+    }
+    r->totals.lastFrameMs = total; r->totals.lastTraceMs = trace; r->totals.lastShadeMs = shade;
+    r->totals.totalMs += total;
+    r->pending[slot] = false;
+}
+
+template <int MODE>
+void launch_primary(RtxRenderer* r, const DevFrame& fr, int workIdx) {
+    if (r->cfg.countStats)
+        hipLaunchKernelGGL((k_primary<MODE, true>), dim3(r->gridTrace), dim3(RTX_BLOCK), r->ldsTrace, r->stream, r->sc, fr, r->dTiles,
+                           r->dRqO[0], r->dRqD[0], r->dHitT, r->dHitLeaf, r->dSeeds, r->dCtrl, r->dStats, workIdx);
+    else
+        hipLaunchKernelGGL((k_primary<MODE, false>), dim3(r->gridTrace), dim3(RTX_BLOCK), r->ldsTrace, r->stream, r->sc, fr, r->dTiles,
+                           r->dRqO[0], r->dRqD[0], r->dHitT, r->dHitLeaf, r->dSeeds, r->dCtrl, r->dStats, workIdx);
+}
+template <int MODE>
+void launch_trace(RtxRenderer* r, const float4* o, const float4* d, int countIdx, int workIdx) {
+    if (r->cfg.countStats)
+        hipLaunchKernelGGL((k_trace<MODE, true>), dim3(r->gridTrace), dim3(RTX_BLOCK), r->ldsTrace, r->stream, r->sc, o, d,
+                           r->dHitT, r->dHitLeaf, r->dCtrl, r->dStats, countIdx, workIdx);
+    else
+        hipLaunchKernelGGL((k_trace<MODE, false>), dim3(r->gridTrace), dim3(RTX_BLOCK), r->ldsTrace, r->stream, r->sc, o, d,
+                           r->dHitT, r->dHitLeaf, r->dCtrl, r->dStats, countIdx, workIdx);
+}
+void dispatch_primary(RtxRenderer* r, const DevFrame& fr, int workIdx) {
+    if (r->mode == RTX_MODE_LINEAR) launch_primary<RTX_MODE_LINEAR>(r, fr, workIdx);
+    else if (r->mode == RTX_MODE_EXACT) launch_primary<RTX_MODE_EXACT>(r, fr, workIdx);
+    else launch_primary<RTX_MODE_CULLED>(r, fr, workIdx);
+}
+void dispatch_trace(RtxRenderer* r, const float4* o, const float4* d, int countIdx, int workIdx) {
+    if (r->mode == RTX_MODE_LINEAR) launch_trace<RTX_MODE_LINEAR>(r, o, d, countIdx, workIdx);
+    else if (r->mode == RTX_MODE_EXACT) launch_trace<RTX_MODE_EXACT>(r, o, d, countIdx, workIdx);
+    else launch_trace<RTX_MODE_CULLED>(r, o, d, countIdx, workIdx);
+}
+
+int check_camera(const RtxCamera* cam) {
+    if (!cam) return fail("camera is NULL");
+    return 0;
+}
+
+} // namespace
+
+// ---------------------------------------------------------------------------------
+extern "C" {
+
+const char* rtx_last_error(void) { return g_err.c_str(); }
+const char* rtx_version(void) { return "raytracer_amd HIP backend 0.1 (gfx950)"; }
+
+void rtx_destroy(RtxRenderer* r) {
+    if (!r) return;
+    hipSetDevice(r->device);
+    if (r->stream) hipStreamSynchronize(r->stream);
+    void* ptrs[] = {r->dInner, r->dLeaf, r->dShade, r->dMaterials, r->dTexInfo, r->dTexels, r->dTiles, r->dRqO[0], r->dRqO[1],
+                    r->dRqD[0], r->dRqD[1], r->dHitT, r->dHitLeaf, r->dLight, r->dAcc, r->dFb, r->dSeeds, r->dCtrl, r->dStats};
+    for (void* p : ptrs) if (p) hipFree(p);
+    for (int2* p : r->dTilesOfRank) if (p) hipFree(p);
+    for (int i = 0; i < kRing; ++i) for (int k = 0; k < kEvents; ++k) if (r->ev[i][k]) hipEventDestroy(r->ev[i][k]);
+    if (r->stream) hipStreamDestroy(r->stream);
+    delete r;
+}
+
+int rtx_create(const RtxSceneDesc* scene, const RtxConfig* cfgIn, RtxRenderer** out) {
+    if (!scene || !out) return fail("rtx_create: NULL argument");
+    *out = nullptr;
+    RtxConfig cfg{};
+    if (cfgIn) cfg = *cfgIn;
+    if (cfg.worldSize <= 0) { cfg.worldSize = 1; cfg.rank = 0; }
+    if (cfg.rank < 0 || cfg.rank >= cfg.worldSize) return fail("rank outside [0, worldSize)");
+    if (cfg.tileW == 0) cfg.tileW = 64;
+    if (cfg.tileH == 0) cfg.tileH = 32;
+    if (cfg.tileW < 8 || cfg.tileH < 8 || (cfg.tileW & 7) || (cfg.tileH & 7) || cfg.tileW > 1024 || cfg.tileH > 1024)
+        return fail("tileW/tileH must be multiples of 8 in [8,1024]");
+    if (scene->width == 0 || scene->height == 0 || scene->width > 32768 || scene->height > 32768) return fail("bad resolution");
+    if (scene->numObjects > 0 && !scene->objects) return fail("objects is NULL");
+    if (scene->numObjects > 0x7fffffffull) return fail("too many objects");
+    if (scene->numMaterials == 0 || !scene->materials) return fail("at least one material is required");
+    if (scene->numTextures == 0 || !scene->textureInfo || !scene->textureData) return fail("at least one texture is required");
+    for (uint64_t i = 0; i < scene->numMaterials; ++i) {
+        const int32_t t = scene->materials[i].textureID;
+        if (t < 0 || (uint64_t)t >= scene->numTextures) return fail("material " + std::to_string(i) + ": textureID out of range");
+    }
+    for (uint64_t i = 0; i < scene->numTextures; ++i) {
+        const RtxTexture& t = scene->textureInfo[i];
+        if (t.width <= 0 || t.height <= 0 || t.width > 4096 || t.height > 65536 || t.offset < 0 ||
+            (uint64_t)t.offset + (uint64_t)t.width * (uint64_t)t.height > scene->numTexels)
+            return fail("texture " + std::to_string(i) + ": extent outside textureData (or wider than 4096)");
+    }
+    // src/ThreadedShader.cpp:15-19
+    const bool useBVH = scene->useBVH && scene->numBoxes > 0;
+    if (useBVH && !scene->boxes) return fail("boxes is NULL");
+
+    Flat flat;
+    if (flatten(*scene, useBVH, flat)) return 1;
+    if (useBVH && flat.maxDepth > 62) return fail("BVH deeper than 62 levels is not supported (the reference's own stack holds 32)");
+
+    RtxRenderer* r = new RtxRenderer();
+    memset(r->ev, 0, sizeof(r->ev));
+    r->cfg = cfg; r->device = cfg.device;
+    r->width = scene->width; r->height = scene->height;
+    r->linear = !useBVH;
+    r->mode = r->linear ? RTX_MODE_LINEAR : (cfg.traversal == RTX_TRAVERSE_EXACT ? RTX_MODE_EXACT : RTX_MODE_CULLED);
+    r->tileW = cfg.tileW; r->tileH = cfg.tileH;
+
+#define CREATE_TRY(expr) do { if (expr) { rtx_destroy(r); return 1; } } while (0)
+#define CREATE_HIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { fail(std::string(#expr) + ": " + hipGetErrorString(e_)); rtx_destroy(r); return 1; } } while (0)
+
+    CREATE_HIP(hipSetDevice(r->device));
+    hipDeviceProp_t prop;
+    CREATE_HIP(hipGetDeviceProperties(&prop, r->device));
+    r->numCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    CREATE_HIP(hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking));
+    for (int i = 0; i < kRing; ++i) for (int k = 0; k < kEvents; ++k) CREATE_HIP(hipEventCreate(&r->ev[i][k]));
+
+    // tiles: tile t (row-major over the tile grid) belongs to rank t % worldSize
+    r->tilesX = (int)((r->width + r->tileW - 1) / r->tileW);
+    r->tilesY = (int)((r->height + r->tileH - 1) / r->tileH);
+    r->tilesOfRank.assign(cfg.worldSize, {});
+    for (int t = 0; t < r->tilesX * r->tilesY; ++t) {
+        int2 org = make_int2((t % r->tilesX) * r->tileW, (t / r->tilesX) * r->tileH);
+        r->tilesOfRank[t % cfg.worldSize].push_back(org);
+    }
+    r->localTiles = r->tilesOfRank[cfg.rank];
+    r->localPixels = 0;
+    for (const int2& t : r->localTiles) {
+        int w = std::min(r->tileW, (int)r->width - t.x), h = std::min(r->tileH, (int)r->height - t.y);
+        r->localPixels += (uint64_t)w * h;
+    }
+    const uint64_t slots = (uint64_t)r->localTiles.size() * r->tileW * r->tileH;
+    if (slots > 0x7fffff00ull) { fail("too many pixels for one rank"); rtx_destroy(r); return 1; }
+    r->numSlots = (uint32_t)slots;
+    r->dTilesOfRank.assign(cfg.worldSize, nullptr);
+    for (int k = 0; k < cfg.worldSize; ++k)
+        CREATE_TRY(upload(&r->dTilesOfRank[k], r->tilesOfRank[k].data(), r->tilesOfRank[k].size() * sizeof(int2)));
+    CREATE_TRY(upload(&r->dTiles, r->localTiles.data(), r->localTiles.size() * sizeof(int2)));
+
+    // scene
+    CREATE_TRY(upload(&r->dInner, flat.inner.data(), flat.inner.size() * sizeof(float4)));
+    CREATE_TRY(upload(&r->dLeaf, flat.leaf.data(), flat.leaf.size() * sizeof(float4)));
+    CREATE_TRY(upload(&r->dShade, flat.shade.data(), flat.shade.size() * sizeof(float4)));
+    CREATE_TRY(upload(&r->dMaterials, scene->materials, scene->numMaterials * sizeof(RtxMaterial)));
+    CREATE_TRY(upload(&r->dTexInfo, scene->textureInfo, scene->numTextures * sizeof(RtxTexture)));
+    CREATE_TRY(upload(&r->dTexels, scene->textureData, scene->numTexels * sizeof(uint32_t),
+                      (scene->numTexels + RTX_TEX_PAD) * sizeof(uint32_t)));
+    r->sc.inner = r->dInner; r->sc.leaf = r->dLeaf; r->sc.shade = r->dShade; r->sc.materials = r->dMaterials;
+    r->sc.texInfo = r->dTexInfo; r->sc.texels = r->dTexels;
+    r->sc.numTexelsPadded = (long long)scene->numTexels + RTX_TEX_PAD;
+    r->sc.rootRef = flat.rootRef;
+    r->sc.numLeaves = (int)(flat.leaf.size() / 4);
+    r->sc.numInner = (int)(flat.inner.size() / 4);
+    r->sc.numMaterials = (int)scene->numMaterials;
+    r->sc.numTextures = (int)scene->numTextures;
+    // textureInfo[1] is hard-wired as the sky (src/ThreadedShader.cpp:162); with a
+    // single texture the reference reads past the vector, here texture 0 is used
+    r->sc.skyTex = scene->numTextures > 1 ? 1 : 0;
+    r->sc.useBVH = useBVH ? 1 : 0;
+    r->sc.stackDepth = std::max(2, flat.maxDepth + 2);
+
+    // per-path state and queues
+    const size_t n = std::max<size_t>(r->numSlots, 64);
+    for (int k = 0; k < 2; ++k) {
+        CREATE_HIP(hipMalloc((void**)&r->dRqO[k], n * sizeof(float4)));
+        CREATE_HIP(hipMalloc((void**)&r->dRqD[k], n * sizeof(float4)));
+    }
+    CREATE_HIP(hipMalloc((void**)&r->dHitT, n * sizeof(float)));
+    CREATE_HIP(hipMalloc((void**)&r->dHitLeaf, n * sizeof(int)));
+    CREATE_HIP(hipMalloc((void**)&r->dLight, n * sizeof(float4)));
+    CREATE_HIP(hipMalloc((void**)&r->dAcc, n * sizeof(float4)));
+    CREATE_HIP(hipMalloc((void**)&r->dSeeds, n * sizeof(uint32_t)));
+    CREATE_HIP(hipMalloc((void**)&r->dCtrl, RTX_CTRL_WORDS * sizeof(uint32_t)));
+    CREATE_HIP(hipMalloc((void**)&r->dStats, RTX_STAT_WORDS * sizeof(unsigned long long)));
+    CREATE_HIP(hipMemset(r->dStats, 0, RTX_STAT_WORDS * sizeof(unsigned long long)));
+    const size_t fbBytes = (size_t)r->width * r->height * sizeof(float4);
+    CREATE_HIP(hipMalloc((void**)&r->dFb, fbBytes));
+    CREATE_HIP(hipMemset(r->dFb, 0, fbBytes));      // zero-filled like src/WindowManager.cpp:26-27
+
+    // launch geometry: persistent grids sized by the LDS the traversal stack needs
+    r->ldsTrace = r->linear ? 0 : (size_t)r->sc.stackDepth * RTX_BLOCK * sizeof(int);
+    int blocksPerCU = 8;
+    if (r->ldsTrace) blocksPerCU = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / r->ldsTrace));
+    r->gridTrace = r->numCUs * blocksPerCU;
+    r->gridShade = r->numCUs * 4;
+    CREATE_HIP(hipDeviceSynchronize());
+    *out = r;
+    return 0;
+}
+
+static int render_frame(RtxRenderer* r, const RtxCamera* cam, uint32_t fc, bool primaryOnly) {
+    HIP_TRY(hipSetDevice(r->device));
+    const int slot = r->ringPos;
+    r->ringPos = (r->ringPos + 1) % kRing;
+    finish_timing(r, slot);
+    const DevFrame fr = make_frame(r, cam, fc);
+    HIP_TRY(hipMemsetAsync(r->dCtrl, 0, RTX_CTRL_WORDS * sizeof(uint32_t), r->stream));
+    hipEvent_t* ev = r->ev[slot];
+    HIP_TRY(hipEventRecord(ev[0], r->stream));
+    dispatch_primary(r, fr, 0);
+    HIP_TRY(hipEventRecord(ev[1], r->stream));
+    if (!primaryOnly) {
+        int in = 0;
+        for (int b = 0; b < 4; ++b) {
+            if (b > 0) {
+                dispatch_trace(r, r->dRqO[in], r->dRqD[in], b, 2 * b);
+                HIP_TRY(hipEventRecord(ev[2 * b + 1], r->stream));
+            }
+            hipLaunchKernelGGL(k_shade, dim3(r->gridShade), dim3(RTX_BLOCK), 0, r->stream, r->sc, fr, r->dTiles, b, r->linear ? 1 : 0,
+                               r->dRqO[in], r->dRqD[in], r->dHitT, r->dHitLeaf, r->dRqO[in ^ 1], r->dRqD[in ^ 1],
+                               r->dLight, r->dAcc, r->dSeeds, r->dFb, r->dCtrl, r->dStats, 2 * b + 1);
+            HIP_TRY(hipEventRecord(ev[2 * b + 2], r->stream));
+            in ^= 1;
+        }
+        hipLaunchKernelGGL(k_fold_counts, dim3(1), dim3(64), 0, r->stream, r->dCtrl, r->dStats, (uint32_t)r->localPixels);
+        HIP_TRY(hipEventRecord(ev[kEvents - 1], r->stream));
+        r->pending[slot] = true;
+        r->totals.frames++;
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+static int copy_out(RtxRenderer* r, float* pixels) {
+    const size_t fbBytes = (size_t)r->width * r->height * sizeof(float4);
+    if (r->cfg.worldSize == 1) {
+        HIP_TRY(hipMemcpyAsync(pixels, r->dFb, fbBytes, hipMemcpyDeviceToHost, r->stream));
+        HIP_TRY(hipStreamSynchronize(r->stream));
+        return 0;
+    }
+    r->hostStage.resize((size_t)r->width * r->height * 4);
+    HIP_TRY(hipMemcpyAsync(r->hostStage.data(), r->dFb, fbBytes, hipMemcpyDeviceToHost, r->stream));
+    HIP_TRY(hipStreamSynchronize(r->stream));
+    for (const int2& t : r->localTiles) {
+        const int w = std::min(r->tileW, (int)r->width - t.x), h = std::min(r->tileH, (int)r->height - t.y);
+        for (int y = 0; y < h; ++y) {
+            const size_t off = ((size_t)(t.y + y) * r->width + t.x) * 4;
+            memcpy(pixels + off, r->hostStage.data() + off, (size_t)w * 4 * sizeof(float));
+        }
+    }
+    return 0;
+}
+
+int rtx_render(RtxRenderer* r, const RtxCamera* camera, uint32_t frameCounter, float* pixels_rgba) {
+    if (!r) return fail("renderer is NULL");
+    if (check_camera(camera)) return 1;
+    if (render_frame(r, camera, frameCounter, false)) return 1;
+    if (pixels_rgba) return copy_out(r, pixels_rgba);
+    return 0;
+}
+
+int rtx_primary_hits(RtxRenderer* r, const RtxCamera* camera, uint32_t frameCounter, int32_t* objectIDs) {
+    if (!r || !objectIDs) return fail("NULL argument");
+    if (check_camera(camera)) return 1;
+    if (render_frame(r, camera, frameCounter, true)) return 1;
+    const size_t npx = (size_t)r->width * r->height;
+    int* dIds = nullptr;
+    HIP_TRY(hipMalloc((void**)&dIds, npx * sizeof(int)));
+    hipError_t e = hipMemsetAsync(dIds, 0xff, npx * sizeof(int), r->stream);
+    const DevFrame fr = make_frame(r, camera, frameCounter);
+    if (e == hipSuccess && r->numSlots) {
+        hipLaunchKernelGGL(k_hits_to_ids, dim3((r->numSlots + 255) / 256), dim3(256), 0, r->stream, r->sc, fr, r->dTiles, r->dHitLeaf, dIds);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(objectIDs, dIds, npx * sizeof(int), hipMemcpyDeviceToHost, r->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(r->stream);
+    hipFree(dIds);
+    if (e != hipSuccess) return fail(std::string("rtx_primary_hits: ") + hipGetErrorString(e));
+    return 0;
+}
+
+int rtx_trace_rays(RtxRenderer* r, const float* origins, const float* directions, uint64_t n,
+                   int32_t* objectIDs, float* points, float* normals) {
+    if (!r || !origins || !directions) return fail("NULL argument");
+    if (n == 0) return 0;
+    if (n > 0x7fffff00ull) return fail("too many rays");
+    HIP_TRY(hipSetDevice(r->device));
+    float4 *dO = nullptr, *dD = nullptr, *dP = nullptr, *dN = nullptr; float* dT = nullptr; int *dL = nullptr, *dI = nullptr;
+    hipError_t e = hipSuccess;
+    auto ok = [&](hipError_t x) { if (e == hipSuccess) e = x; return e == hipSuccess; };
+    ok(hipMalloc((void**)&dO, n * sizeof(float4))); ok(hipMalloc((void**)&dD, n * sizeof(float4)));
+    ok(hipMalloc((void**)&dP, n * sizeof(float4))); ok(hipMalloc((void**)&dN, n * sizeof(float4)));
+    ok(hipMalloc((void**)&dT, n * sizeof(float))); ok(hipMalloc((void**)&dL, n * sizeof(int))); ok(hipMalloc((void**)&dI, n * sizeof(int)));
+    if (e == hipSuccess) {
+        ok(hipMemcpyAsync(dO, origins, n * sizeof(float4), hipMemcpyHostToDevice, r->stream));
+        ok(hipMemcpyAsync(dD, directions, n * sizeof(float4), hipMemcpyHostToDevice, r->stream));
+        ok(hipMemsetAsync(r->dCtrl, 0, RTX_CTRL_WORDS * sizeof(uint32_t), r->stream));
+        uint32_t cnt = (uint32_t)n;
+        ok(hipMemcpyAsync(r->dCtrl + RTX_CTRL_COUNT(1), &cnt, sizeof(cnt), hipMemcpyHostToDevice, r->stream));
+        ok(hipStreamSynchronize(r->stream));   // cnt is a stack variable
+    }
+    if (e == hipSuccess) {
+        float* saveT = r->dHitT; int* saveL = r->dHitLeaf;
+        r->dHitT = dT; r->dHitLeaf = dL;
+        dispatch_trace(r, dO, dD, 1, 0);
+        r->dHitT = saveT; r->dHitLeaf = saveL;
+        hipLaunchKernelGGL(k_probe_finish, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, r->stream, r->sc, r->linear ? 1 : 0,
+                           dO, dD, dT, dL, (uint32_t)n, dI, dP, dN);
+        ok(hipGetLastError());
+        if (objectIDs) ok(hipMemcpyAsync(objectIDs, dI, n * sizeof(int), hipMemcpyDeviceToHost, r->stream));
+        if (points) ok(hipMemcpyAsync(points, dP, n * sizeof(float4), hipMemcpyDeviceToHost, r->stream));
+        if (normals) ok(hipMemcpyAsync(normals, dN, n * sizeof(float4), hipMemcpyDeviceToHost, r->stream));
+        ok(hipStreamSynchronize(r->stream));
+    }
+    void* ptrs[] = {dO, dD, dP, dN, dT, dL, dI};
+    for (void* p : ptrs) if (p) hipFree(p);
+    if (e != hipSuccess) return fail(std::string("rtx_trace_rays: ") + hipGetErrorString(e));
+    return 0;
+}
+
+int rtx_upload_pixels(RtxRenderer* r, const float* pixels) {
+    if (!r || !pixels) return fail("NULL argument");
+    HIP_TRY(hipSetDevice(r->device));
+    HIP_TRY(hipMemcpyAsync(r->dFb, pixels, (size_t)r->width * r->height * sizeof(float4), hipMemcpyHostToDevice, r->stream));
+    HIP_TRY(hipStreamSynchronize(r->stream));
+    return 0;
+}
+int rtx_download_pixels(RtxRenderer* r, float* pixels) {
+    if (!r || !pixels) return fail("NULL argument");
+    HIP_TRY(hipSetDevice(r->device));
+    HIP_TRY(hipMemcpyAsync(pixels, r->dFb, (size_t)r->width * r->height * sizeof(float4), hipMemcpyDeviceToHost, r->stream));
+    HIP_TRY(hipStreamSynchronize(r->stream));
+    return 0;
+}
+int rtx_clear_pixels(RtxRenderer* r) {
+    if (!r) return fail("NULL argument");
+    HIP_TRY(hipSetDevice(r->device));
+    HIP_TRY(hipMemsetAsync(r->dFb, 0, (size_t)r->width * r->height * sizeof(float4), r->stream));
+    return 0;
+}
+
+int rtx_get_counters(RtxRenderer* r, RtxCounters* out) {
+    if (!r || !out) return fail("NULL argument");
+    HIP_TRY(hipSetDevice(r->device));
+    HIP_TRY(hipStreamSynchronize(r->stream));
+    // oldest pending frame first so that lastFrameMs ends up describing the newest one
+    for (int i = 0; i < kRing; ++i) finish_timing(r, (r->ringPos + i) % kRing);
+    unsigned long long st[RTX_STAT_WORDS];
+    HIP_TRY(hipMemcpy(st, r->dStats, sizeof(st), hipMemcpyDeviceToHost));
+    RtxCounters c = r->totals;
+    c.rays = 0;
+    for (int b = 0; b < 4; ++b) { c.raysPerBounce[b] = st[RTX_STAT_RAYS(b)]; c.hitsPerBounce[b] = st[RTX_STAT_HITS(b)]; c.rays += st[RTX_STAT_RAYS(b)]; }
+    c.innerVisits = st[RTX_STAT_INNER]; c.leafTests = st[RTX_STAT_LEAF];
+    *out = c;
+    return 0;
+}
+int rtx_reset_counters(RtxRenderer* r) {
+    if (!r) return fail("NULL argument");
+    HIP_TRY(hipSetDevice(r->device));
+    HIP_TRY(hipStreamSynchronize(r->stream));
+    for (int i = 0; i < kRing; ++i) finish_timing(r, i);
+    HIP_TRY(hipMemset(r->dStats, 0, RTX_STAT_WORDS * sizeof(unsigned long long)));
+    r->totals = RtxCounters{};
+    return 0;
+}
+
+void* rtx_framebuffer_device_ptr(RtxRenderer* r) { return r ? (void*)r->dFb : nullptr; }
+void* rtx_stream(RtxRenderer* r) { return r ? (void*)r->stream : nullptr; }
+uint64_t rtx_local_pixel_count(RtxRenderer* r) { return r ? r->localPixels : 0; }
+uint32_t rtx_local_tile_count(RtxRenderer* r) { return r ? (uint32_t)r->localTiles.size() : 0; }
+uint64_t rtx_packed_floats(RtxRenderer* r, int32_t rank) {
+    if (!r || rank < 0 || rank >= r->cfg.worldSize) return 0;
+    return (uint64_t)r->tilesOfRank[rank].size() * r->tileW * r->tileH * 4;
+}
+int rtx_pack_tiles(RtxRenderer* r, void* d_packed) {
+    if (!r || !d_packed) return fail("NULL argument");
+    HIP_TRY(hipSetDevice(r->device));
+    const uint64_t total = (uint64_t)r->localTiles.size() * r->tileW * r->tileH;
+    if (total == 0) return 0;
+    RtxCamera dummy{}; const DevFrame fr = make_frame(r, &dummy, 0);
+    hipLaunchKernelGGL(k_pack_tiles, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, r->stream, fr, r->dTiles,
+                       (int)r->localTiles.size(), r->dFb, (float4*)d_packed);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(r->stream));
+    return 0;
+}
+int rtx_unpack_tiles(RtxRenderer* r, const void* d_packed, int32_t srcRank) {
+    if (!r || !d_packed) return fail("NULL argument");
+    if (srcRank < 0 || srcRank >= r->cfg.worldSize) return fail("srcRank out of range");
+    HIP_TRY(hipSetDevice(r->device));
+    const uint64_t total = (uint64_t)r->tilesOfRank[srcRank].size() * r->tileW * r->tileH;
+    if (total == 0) return 0;
+    RtxCamera dummy{}; const DevFrame fr = make_frame(r, &dummy, 0);
+    hipLaunchKernelGGL(k_unpack_tiles, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, r->stream, fr, r->dTilesOfRank[srcRank],
+                       (int)r->tilesOfRank[srcRank].size(), (const float4*)d_packed, r->dFb);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(r->stream));
+    return 0;
+}
+
+} // extern "C"

@@ -1,0 +1,279 @@
+// rtx_kernels.h — the per-frame kernels of the HIP backend.
+//
+// Frame pipeline (one stream, no host round trip inside a frame):
+//   k_primary            slot -> pixel, seed, jitter, primary ray, closest hit        (bounce 0)
+//   k_shade   (bounce b) sky or material shading, running-mean write-back of finished
+//                        paths, surviving paths compacted into the next ray queue
+//   k_trace   (bounce b) closest hit for the queued rays                              (b = 1..3)
+// Every kernel is a persistent grid whose waves pull 64-item chunks from a device
+// counter, so queue lengths never have to travel to the host. Surviving rays are
+// regrouped between bounces by wave ballot + prefix popcount (one atomic per wave),
+// so every trace launch runs on dense waves whatever the path mortality was.
+// Per-path state (ray, light, accumulator, seed) lives in SoA arrays indexed by
+// the path's slot; slots enumerate this rank's screen tiles in 8x8-pixel blocks,
+// one block per wave, so a wave's primary rays are spatially coherent.
+#pragma once
+#include "rtx_device.h"
+#include "rtx_traverse.h"
+#include "rtx_shade.h"
+
+#define RTX_BLOCK 256
+#define RTX_MODE_CULLED 0
+#define RTX_MODE_EXACT 1
+#define RTX_MODE_LINEAR 2
+#define RTX_INVALID_SLOT (-2)
+
+// ctrl[] layout (uint32): [0..7] queue counts per bounce, [8..23] work counters per launch
+#define RTX_CTRL_COUNT(b) (b)
+#define RTX_CTRL_WORK(k) (8 + (k))
+#define RTX_CTRL_WORDS 32
+// stats[] layout (uint64)
+#define RTX_STAT_INNER 0
+#define RTX_STAT_LEAF 1
+#define RTX_STAT_RAYS(b) (2 + (b))
+#define RTX_STAT_HITS(b) (6 + (b))
+#define RTX_STAT_WORDS 16
+
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// next 64-item chunk for this wave (wave-uniform)
+__device__ __forceinline__ uint32_t next_chunk(uint32_t* counter) {
+    uint32_t base = 0;
+    if ((threadIdx.x & 63) == 0) base = atomicAdd(counter, 64u);
+    return __builtin_amdgcn_readfirstlane(base);
+}
+
+__device__ __forceinline__ bool slot_to_pixel(const DevFrame& fr, const int2* __restrict__ tiles, uint32_t slot, int& x, int& y) {
+    const uint32_t perTile = (uint32_t)(fr.tileW * fr.tileH);
+    const uint32_t tile = slot / perTile, within = slot % perTile;
+    const int2 org = tiles[tile];
+    const uint32_t blk = within >> 6, l = within & 63u;
+    const uint32_t blocksX = (uint32_t)fr.tileW >> 3;
+    x = org.x + (int)((blk % blocksX) << 3) + (int)(l & 7u);
+    y = org.y + (int)((blk / blocksX) << 3) + (int)(l >> 3);
+    return x < fr.width && y < fr.height;
+}
+
+template <int MODE, bool COUNT>
+__device__ __forceinline__ Hit closest_hit(const DevScene& sc, float ox, float oy, float oz, float dx, float dy, float dz,
+                                           int* stack, uint32_t& ic, uint32_t& lc) {
+    if (MODE == RTX_MODE_LINEAR) return traverse_linear<COUNT>(sc, ox, oy, oz, dx, dy, dz, lc);
+    return traverse_bvh<MODE == RTX_MODE_EXACT, COUNT>(sc, ox, oy, oz, dx, dy, dz, stack, RTX_BLOCK, ic, lc);
+}
+
+// src/ThreadedShader.cpp:141-149 + src/Camera.h:57-64
+__device__ __forceinline__ void primary_ray(const DevFrame& fr, int x, int y, uint32_t& seed, F4& o, F4& d) {
+    uint32_t index = (uint32_t)(y * fr.width + x);
+    seed = (fr.frameCounter << 16) ^ ((fr.frameCounter >> 13) + index);
+    F4 offset = random_direction(seed);
+    int px = (int)((float)x + offset.x);
+    int py = (int)((float)y + offset.y);
+    float cameraX = (float)((2.0 * (double)px / (double)(float)fr.width - 1.0) * (double)fr.aspect * (double)fr.tanHalfFOV * (double)fr.nearView);
+    float cameraY = (float)((2.0 * (double)py / (double)(float)fr.height - 1.0) * (double)fr.tanHalfFOV * (double)fr.nearView);
+    F4 pos = mk4(fr.pos[0], fr.pos[1], fr.pos[2]);
+    F4 p = add4(pos, mul4(mk4(fr.front[0], fr.front[1], fr.front[2]), fr.nearView));
+    p = add4(p, mul4(mk4(fr.right[0], fr.right[1], fr.right[2]), cameraX));
+    p = add4(p, mul4(mk4(fr.up[0], fr.up[1], fr.up[2]), cameraY));
+    o = pos;
+    d = normalize4(sub4(p, o));
+}
+
+template <int MODE, bool COUNT>
+__global__ __launch_bounds__(RTX_BLOCK) void k_primary(DevScene sc, DevFrame fr, const int2* __restrict__ tiles,
+                                                       float4* __restrict__ rqO, float4* __restrict__ rqD,
+                                                       float* __restrict__ hitT, int* __restrict__ hitLeaf,
+                                                       uint32_t* __restrict__ seeds, uint32_t* __restrict__ ctrl,
+                                                       unsigned long long* __restrict__ stats, int workIdx) {
+    extern __shared__ int lds[];
+    int* stack = lds + threadIdx.x;
+    uint32_t ic = 0, lc = 0;
+    for (;;) {
+        const uint32_t base = next_chunk(&ctrl[RTX_CTRL_WORK(workIdx)]);
+        if (base >= (uint32_t)fr.numSlots) break;
+        const uint32_t slot = base + (threadIdx.x & 63u);
+        int x, y;
+        if (slot_to_pixel(fr, tiles, slot, x, y)) {
+            uint32_t seed; F4 o, d;
+            primary_ray(fr, x, y, seed, o, d);
+            Hit h = closest_hit<MODE, COUNT>(sc, o.x, o.y, o.z, d.x, d.y, d.z, stack, ic, lc);
+            rqO[slot] = make_float4(o.x, o.y, o.z, __int_as_float((int)slot));
+            rqD[slot] = make_float4(d.x, d.y, d.z, 0.0f);
+            hitT[slot] = h.t;
+            hitLeaf[slot] = h.leaf;
+            seeds[slot] = seed;
+        } else {
+            hitLeaf[slot] = RTX_INVALID_SLOT;
+        }
+    }
+    if (COUNT) {
+        ic = wave_sum(ic); lc = wave_sum(lc);
+        if ((threadIdx.x & 63) == 0) { atomicAdd(&stats[RTX_STAT_INNER], (unsigned long long)ic); atomicAdd(&stats[RTX_STAT_LEAF], (unsigned long long)lc); }
+    }
+}
+
+template <int MODE, bool COUNT>
+__global__ __launch_bounds__(RTX_BLOCK) void k_trace(DevScene sc, const float4* __restrict__ rqO, const float4* __restrict__ rqD,
+                                                     float* __restrict__ hitT, int* __restrict__ hitLeaf,
+                                                     uint32_t* __restrict__ ctrl, unsigned long long* __restrict__ stats,
+                                                     int countIdx, int workIdx) {
+    extern __shared__ int lds[];
+    int* stack = lds + threadIdx.x;
+    uint32_t ic = 0, lc = 0;
+    const uint32_t count = ctrl[RTX_CTRL_COUNT(countIdx)];
+    for (;;) {
+        const uint32_t base = next_chunk(&ctrl[RTX_CTRL_WORK(workIdx)]);
+        if (base >= count) break;
+        const uint32_t q = base + (threadIdx.x & 63u);
+        if (q < count) {
+            float4 o = rqO[q], d = rqD[q];
+            Hit h = closest_hit<MODE, COUNT>(sc, o.x, o.y, o.z, d.x, d.y, d.z, stack, ic, lc);
+            hitT[q] = h.t;
+            hitLeaf[q] = h.leaf;
+        }
+    }
+    if (COUNT) {
+        ic = wave_sum(ic); lc = wave_sum(lc);
+        if ((threadIdx.x & 63) == 0) { atomicAdd(&stats[RTX_STAT_INNER], (unsigned long long)ic); atomicAdd(&stats[RTX_STAT_LEAF], (unsigned long long)lc); }
+    }
+}
+
+// src/ThreadedShader.cpp:155-180 for bounce `bounce` of every queued path.
+__global__ __launch_bounds__(RTX_BLOCK) void k_shade(DevScene sc, DevFrame fr, const int2* __restrict__ tiles, int bounce, int linearMode,
+                                                     const float4* __restrict__ rqOin, const float4* __restrict__ rqDin,
+                                                     const float* __restrict__ hitT, const int* __restrict__ hitLeaf,
+                                                     float4* __restrict__ rqOout, float4* __restrict__ rqDout,
+                                                     float4* __restrict__ lightArr, float4* __restrict__ accArr,
+                                                     uint32_t* __restrict__ seeds, float4* __restrict__ fb,
+                                                     uint32_t* __restrict__ ctrl, unsigned long long* __restrict__ stats, int workIdx) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t count = bounce == 0 ? (uint32_t)fr.numSlots : ctrl[RTX_CTRL_COUNT(bounce)];
+    const F4 camPos = mk4(fr.pos[0], fr.pos[1], fr.pos[2]);
+    uint32_t hits = 0;
+    for (;;) {
+        const uint32_t base = next_chunk(&ctrl[RTX_CTRL_WORK(workIdx)]);
+        if (base >= count) break;
+        const uint32_t q = base + lane;
+        bool active = q < count;
+        int leaf = -1;
+        if (active) { leaf = hitLeaf[q]; active = leaf != RTX_INVALID_SLOT; }
+        bool alive = false;
+        F4 o = mk4(0, 0, 0), d = mk4(0, 0, 0), light = mk4(1, 1, 1, 1), acc = mk4(0, 0, 0, 0);
+        uint32_t seed = 0; int slot = 0;
+        if (active) {
+            float4 o4 = rqOin[q], d4 = rqDin[q];
+            slot = __float_as_int(o4.w);
+            o = mk4(o4.x, o4.y, o4.z); d = mk4(d4.x, d4.y, d4.z);
+            if (bounce > 0) { light = from4(lightArr[slot]); acc = from4(accArr[slot]); }
+            bool finished;
+            if (leaf < 0) {
+                F4 texel = sky_texel(sc, d);
+                acc = add4(acc, mul4(texel, light));          // no clamp on the sky term (src/ThreadedShader.cpp:169)
+                finished = true;
+            } else {
+                hits++;
+                seed = seeds[slot];
+                HitPrim prim = load_prim(sc, leaf);
+                float t = hitT[q];
+                F4 dirForPoint = linearMode ? mul4(d, 1.0000001f) : d;   // src/ThreadedShader.cpp:217,232
+                F4 point = add4(o, mul4(dirForPoint, t));
+                F4 normal = hit_normal(prim, point);
+                F4 color = compute_color(sc, camPos, o, d, point, normal, prim, light, seed);
+                light = clamp01_sse(light);
+                acc = clamp01_sse(add4(acc, color));
+                finished = bounce == 3;
+            }
+            if (finished) {
+                int x, y;
+                slot_to_pixel(fr, tiles, (uint32_t)slot, x, y);
+                size_t pix = (size_t)y * (size_t)fr.width + (size_t)x;
+                F4 prev = from4(fb[pix]);
+                F4 res = lerp_color(prev, acc, fr.lerpScale);  // src/ThreadedShader.cpp:179-180
+                fb[pix] = make_float4(res.x, res.y, res.z, res.w);
+            } else {
+                alive = true;
+            }
+        }
+        // regroup survivors: dense positions in the next queue
+        const unsigned long long m = __ballot(alive);
+        if (m) {
+            uint32_t qbase = 0;
+            if (lane == 0) qbase = atomicAdd(&ctrl[RTX_CTRL_COUNT(bounce + 1)], (uint32_t)__popcll(m));
+            qbase = __builtin_amdgcn_readfirstlane(qbase);
+            if (alive) {
+                const uint32_t pos = qbase + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                rqOout[pos] = make_float4(o.x, o.y, o.z, __int_as_float(slot));
+                rqDout[pos] = make_float4(d.x, d.y, d.z, 0.0f);
+                lightArr[slot] = make_float4(light.x, light.y, light.z, light.w);
+                accArr[slot] = make_float4(acc.x, acc.y, acc.z, acc.w);
+                seeds[slot] = seed;
+            }
+        }
+    }
+    hits = wave_sum(hits);
+    if (lane == 0 && hits) atomicAdd(&stats[RTX_STAT_HITS(bounce)], (unsigned long long)hits);
+}
+
+// after the last shade: fold this frame's queue lengths into the 64-bit totals
+__global__ void k_fold_counts(const uint32_t* __restrict__ ctrl, unsigned long long* __restrict__ stats, uint32_t primaryRays) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        stats[RTX_STAT_RAYS(0)] += primaryRays;
+        for (int b = 1; b < 4; ++b) stats[RTX_STAT_RAYS(b)] += ctrl[RTX_CTRL_COUNT(b)];
+    }
+}
+
+// ---- probes -------------------------------------------------------------------
+__global__ void k_hits_to_ids(DevScene sc, DevFrame fr, const int2* __restrict__ tiles, const int* __restrict__ hitLeaf, int* __restrict__ ids) {
+    uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= (uint32_t)fr.numSlots) return;
+    int x, y;
+    if (!slot_to_pixel(fr, tiles, slot, x, y)) return;
+    int leaf = hitLeaf[slot];
+    int id = -1;
+    if (leaf >= 0) id = __float_as_int(sc.leaf[(size_t)leaf * 4 + 2].y);
+    ids[(size_t)y * fr.width + x] = id;
+}
+
+__global__ void k_probe_finish(DevScene sc, int linearMode, const float4* __restrict__ rqO, const float4* __restrict__ rqD,
+                               const float* __restrict__ hitT, const int* __restrict__ hitLeaf, uint32_t n,
+                               int* __restrict__ ids, float4* __restrict__ points, float4* __restrict__ normals) {
+    uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n) return;
+    int leaf = hitLeaf[q];
+    int id = -1; F4 point = mk4(0, 0, 0), normal = mk4(0, 0, 0);
+    if (leaf >= 0) {
+        HitPrim prim = load_prim(sc, leaf);
+        id = __float_as_int(sc.leaf[(size_t)leaf * 4 + 2].y);
+        float4 o4 = rqO[q], d4 = rqD[q];
+        F4 o = mk4(o4.x, o4.y, o4.z), d = mk4(d4.x, d4.y, d4.z);
+        F4 dirForPoint = linearMode ? mul4(d, 1.0000001f) : d;
+        point = add4(o, mul4(dirForPoint, hitT[q]));
+        normal = hit_normal(prim, point);
+    }
+    ids[q] = id;
+    points[q] = make_float4(point.x, point.y, point.z, 0.0f);
+    normals[q] = make_float4(normal.x, normal.y, normal.z, 0.0f);
+}
+
+// ---- multi-GPU tile plumbing ----------------------------------------------------
+// packed layout: tile k of the rank at k*tileW*tileH float4, row-major inside the tile
+__global__ void k_pack_tiles(DevFrame fr, const int2* __restrict__ tiles, int numTiles, const float4* __restrict__ fb, float4* __restrict__ packed) {
+    const uint32_t perTile = (uint32_t)(fr.tileW * fr.tileH);
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (uint64_t)numTiles * perTile) return;
+    uint32_t tile = (uint32_t)(i / perTile), within = (uint32_t)(i % perTile);
+    int x = tiles[tile].x + (int)(within % (uint32_t)fr.tileW), y = tiles[tile].y + (int)(within / (uint32_t)fr.tileW);
+    float4 v = make_float4(0, 0, 0, 0);
+    if (x < fr.width && y < fr.height) v = fb[(size_t)y * fr.width + x];
+    packed[i] = v;
+}
+__global__ void k_unpack_tiles(DevFrame fr, const int2* __restrict__ tiles, int numTiles, const float4* __restrict__ packed, float4* __restrict__ fb) {
+    const uint32_t perTile = (uint32_t)(fr.tileW * fr.tileH);
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (uint64_t)numTiles * perTile) return;
+    uint32_t tile = (uint32_t)(i / perTile), within = (uint32_t)(i % perTile);
+    int x = tiles[tile].x + (int)(within % (uint32_t)fr.tileW), y = tiles[tile].y + (int)(within / (uint32_t)fr.tileW);
+    if (x < fr.width && y < fr.height) fb[(size_t)y * fr.width + x] = packed[i];
+}

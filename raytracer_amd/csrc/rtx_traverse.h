@@ -1,0 +1,149 @@
+// rtx_traverse.h — closest-hit query over the flattened BVH (or the linear list).
+//
+// Semantics reproduced (src/ThreadedShader.cpp:337-395, :209-237):
+//   * a leaf is tested iff every box on its root path passes AABBIntersection
+//     (the reference never culls by distance; the root itself is not tested);
+//   * a hit is accepted iff t < best && t > 0.01f; the reference visits leaves in
+//     descending boxID, so among equal t the LARGEST leaf boxID wins (BVH) /
+//     the LOWEST object id wins (linear list);
+//   * t is computed with the reference's operation sequence.
+// RTX_TRAVERSE_EXACT visits exactly that leaf set. RTX_TRAVERSE_CULLED orders
+// children near-first and drops a child whose slab entry distance lies beyond
+// the current best hit by more than a relative slack; every box on the way down
+// is still tested with the reference's own test, so the visited set is a subset
+// of the reference's and the winner is the same unless a triangle's computed t
+// undercuts its own box's computed entry distance by more than the slack
+// (DESIGN.md "Culling"). Lanes whose direction has a zero / non-finite component
+// (0*inf = NaN in the slab test) never cull.
+#pragma once
+#include "rtx_device.h"
+
+#define RTX_NO_CHILD ((int)0x80000000)
+#define RTX_CULL_SLACK 0.00390625f   // 2^-8
+
+struct Hit { float t; int leaf; int box; };
+
+// src/ThreadedShader.cpp:275-289; returns pass flag and tNear
+__device__ __forceinline__ bool slab_test(float ox, float oy, float oz, float ix, float iy, float iz,
+                                          float lx, float ly, float lz, float hx, float hy, float hz, float& tNearOut) {
+    float tminx = (lx - ox) * ix, tminy = (ly - oy) * iy, tminz = (lz - oz) * iz;
+    float tmaxx = (hx - ox) * ix, tmaxy = (hy - oy) * iy, tmaxz = (hz - oz) * iz;
+    float t1x = sse_min(tminx, tmaxx), t1y = sse_min(tminy, tmaxy), t1z = sse_min(tminz, tmaxz);
+    float t2x = sse_max(tminx, tmaxx), t2y = sse_max(tminy, tmaxy), t2z = sse_max(tminz, tmaxz);
+    float tNear = fmaxf(t1x, fmaxf(t1y, t1z));
+    float tFar = fminf(t2x, fminf(t2y, t2z));
+    tNearOut = tNear;
+    return tNear <= tFar && tFar > 0.0f;
+}
+
+// src/ThreadedShader.cpp:291-321 with e1, e2 pre-subtracted
+__device__ __forceinline__ float intersect_triangle(float ox, float oy, float oz, float dx, float dy, float dz,
+                                                    float ax, float ay, float az, float e1x, float e1y, float e1z,
+                                                    float e2x, float e2y, float e2z) {
+    // normal = cross(dir, e2)
+    float nx = dy * e2z - e2y * dz;
+    float ny = -(dx * e2z - e2x * dz);
+    float nz = dx * e2y - e2x * dy;
+    float det = e1x * nx + e1y * ny + e1z * nz;
+    if (fabsf(det) < 1e-6f) return -1.0f;
+    float f = 1.0f / det;
+    float sx = ox - ax, sy = oy - ay, sz = oz - az;
+    float u = f * (sx * nx + sy * ny + sz * nz);
+    if (u < 0.0f || u > 1.0f) return -1.0f;
+    // q = cross(s, e1)
+    float qx = sy * e1z - e1y * sz;
+    float qy = -(sx * e1z - e1x * sz);
+    float qz = sx * e1y - e1x * sy;
+    float v = f * (dx * qx + dy * qy + dz * qz);
+    if (v < 0.0f || (u + v) > 1.0f) return -1.0f;
+    return f * (e2x * qx + e2y * qy + e2z * qz);
+}
+
+// src/ThreadedShader.cpp:323-335 (NaN when the ray misses; rejected by the caller's compares)
+__device__ __forceinline__ float intersect_sphere(float ox, float oy, float oz, float dx, float dy, float dz,
+                                                  float cx, float cy, float cz, float radius) {
+    float ocx = ox - cx, ocy = oy - cy, ocz = oz - cz;
+    float b = ocx * dx + ocy * dy + ocz * dz;
+    float c = (ocx * ocx + ocy * ocy + ocz * ocz) - radius * radius;
+    float delta = b * b - c;
+    float sq = sqrtf(delta);
+    float t1 = (-b - sq);
+    float t2 = (-b + sq);
+    return fminf(t1, t2);
+}
+
+__device__ __forceinline__ float intersect_leaf(const float4* __restrict__ leafBase, int leafIdx,
+                                                float ox, float oy, float oz, float dx, float dy, float dz,
+                                                int& boxOut) {
+    const float4* L = leafBase + (size_t)leafIdx * 4;
+    float4 q0 = L[0], q1 = L[1], q2 = L[2];
+    boxOut = __float_as_int(q2.z);
+    int type = __float_as_int(q2.w);
+    if (type == 4 /* RTX_TRIANGLE */)
+        return intersect_triangle(ox, oy, oz, dx, dy, dz, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x);
+    return intersect_sphere(ox, oy, oz, dx, dy, dz, q0.x, q0.y, q0.z, q0.w);
+}
+
+// BVH closest hit. `stack` is this lane's LDS stack: entry k at stack[k * stride].
+template <bool EXACT, bool COUNT>
+__device__ __forceinline__ Hit traverse_bvh(const DevScene& sc, float ox, float oy, float oz, float dx, float dy, float dz,
+                                            int* stack, int stride, uint32_t& innerCount, uint32_t& leafCount) {
+    Hit best; best.t = INFINITY; best.leaf = -1; best.box = -1;
+    const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;
+    // culling is only enabled for lanes whose slab arithmetic cannot produce NaN from 0*inf
+    bool cull = false;
+    if (!EXACT) cull = (dx != 0.0f) && (dy != 0.0f) && (dz != 0.0f) && isfinite(ix) && isfinite(iy) && isfinite(iz);
+    int sp = 0;
+    int cur = sc.rootRef;
+    const int maxSp = sc.stackDepth;
+    for (;;) {
+        if (cur >= 0) {
+            const float4* N = sc.inner + (size_t)cur * 4;
+            float4 q0 = N[0], q1 = N[1], q2 = N[2], q3 = N[3];
+            if (COUNT) innerCount++;
+            float tn0, tn1;
+            bool p0 = slab_test(ox, oy, oz, ix, iy, iz, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tn0);
+            bool p1 = slab_test(ox, oy, oz, ix, iy, iz, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, tn1);
+            int c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
+            p0 = p0 && (c0 != RTX_NO_CHILD);   // absent child (-1 in the reference's boxes, src/ThreadedShader.cpp:380,387)
+            p1 = p1 && (c1 != RTX_NO_CHILD);
+            if (cull) {
+                float limit = best.t + best.t * RTX_CULL_SLACK;   // inf while nothing is hit
+                p0 = p0 && !(tn0 > limit);
+                p1 = p1 && !(tn1 > limit);
+            }
+            if (p0 && p1) {
+                // near child first; the far one waits on the stack
+                bool swap = tn1 < tn0;
+                int nearC = swap ? c1 : c0, farC = swap ? c0 : c1;
+                if (sp < maxSp) { stack[sp * stride] = farC; sp++; }
+                cur = nearC;
+                continue;
+            } else if (p0) { cur = c0; continue; }
+            else if (p1) { cur = c1; continue; }
+        } else {
+            int leafIdx = ~cur, box;
+            float t = intersect_leaf(sc.leaf, leafIdx, ox, oy, oz, dx, dy, dz, box);
+            if (COUNT) leafCount++;
+            if (t > 0.01f && (t < best.t || (t == best.t && best.leaf >= 0 && box > best.box))) { best.t = t; best.leaf = leafIdx; best.box = box; }
+        }
+        if (sp == 0) break;
+        sp--;
+        cur = stack[sp * stride];
+    }
+    return best;
+}
+
+// Linear list (src/ThreadedShader.cpp:219-237): leaves are stored in object order.
+template <bool COUNT>
+__device__ __forceinline__ Hit traverse_linear(const DevScene& sc, float ox, float oy, float oz, float dx, float dy, float dz,
+                                               uint32_t& leafCount) {
+    Hit best; best.t = INFINITY; best.leaf = -1; best.box = -1;
+    for (int i = 0; i < sc.numLeaves; ++i) {
+        int box;
+        float t = intersect_leaf(sc.leaf, i, ox, oy, oz, dx, dy, dz, box);
+        if (COUNT) leafCount++;
+        if ((t < best.t) && (t > 0.01f)) { best.t = t; best.leaf = i; best.box = box; }
+    }
+    return best;
+}
