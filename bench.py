@@ -1,0 +1,217 @@
+#!/usr/bin/env python3
+"""bench.py — frame-render hot path on N MI355X (one process per GPU).
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+A step = one frame = one sample per pixel over the whole image (the reference's
+"N spp" is N accumulated frames). Default workload = BASELINE.json
+configs[3] shape: synthetic 10 M-triangle mesh + textured materials, 3840x2160
+(rendered at 3840x2176 after the reference's rounding to multiples of 32), scene
+replicated on every GPU, screen tiles dealt round-robin to the ranks, tiles
+gathered to rank 0 once at the end of the timed batch (RCCL). Total work is the
+same for every N (strong scaling). The frame stays resident in HBM; the optional
+device-to-host copy is reported separately (--d2h), never inside `value`.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+
+WORKLOADS = {
+    # name: (triangles, width, height, textured)
+    "cfg4_10Mtri_4k": (10_000_000, 3840, 2160, True),
+    "cfg3_1Mtri_1080p": (1_000_000, 1920, 1080, False),
+    "cfg5_100Mtri_4k": (100_000_000, 3840, 2160, True),
+    "small_100ktri_992": (100_000, 1000, 1000, True),
+}
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="cfg4_10Mtri_4k", choices=sorted(WORKLOADS))
+    ap.add_argument("--traversal", default="culled", choices=["culled", "exact"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--d2h", action="store_true", help="also time K frames with the host copy (reported in `extra`)")
+    ap.add_argument("--orbit", action="store_true", help="-O camera: new camera + frameCounter=0 every frame (src/Main.cpp:68-82)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP backend has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from raytracer_amd import _capi
+    from raytracer_amd.dist import DeviceGather
+    from raytracer_amd.renderer import HIPShader
+    from raytracer_amd.scene import orbit as orbit_camera, synthetic_scene
+
+    ntri, w, h, textured = WORKLOADS[args.workload]
+    cores = max(1, min(16, os.cpu_count() or 1))
+    t0 = time.time()
+    scene = synthetic_scene(ntri, w, h, seed=12345, textured=textured, nthreads=cores)
+    t_scene = time.time() - t0
+    trav = _capi.TRAVERSE_EXACT if args.traversal == "exact" else _capi.TRAVERSE_CULLED
+    t0 = time.time()
+    shader = HIPShader(scene, device=local_rank, rank=rank, world_size=world, traversal=trav)
+    t_create = time.time() - t0
+    W, H = shader.width, shader.height
+    gather = DeviceGather(shader, rank, world, torch.device("cuda", local_rank)) if world > 1 else None
+    cam = scene.camera
+
+    def step(i):
+        if args.orbit:
+            orbit_camera(cam, 0.1 * i, 0.1 * i)
+            shader.frame_counter = 0
+            shader.Render(None, cam)
+        else:
+            shader.frame_counter = i
+            shader.Render(None, cam)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        shader.counters()            # synchronises the renderer's own stream
+
+    for i in range(args.warmup):
+        step(i)
+    if gather is not None:
+        gather.gather()
+    barrier()
+    shader.reset_counters()
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    if gather is not None:
+        gather.gather()                # one exchange per delivered frame batch
+    c = shader.counters()              # stream sync
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+
+    rays_local = float(c.rays)
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    rsum = torch.tensor([rays_local], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(rsum, op=dist.ReduceOp.SUM)
+    elapsed = float(t.item())
+    rays = float(rsum.item())
+    kernel_ms = [x / max(1, c.frames) for x in c.kernelMs]
+    rays_per_bounce = [int(x) for x in c.raysPerBounce]
+    hits_per_bounce = [int(x) for x in c.hitsPerBounce]
+
+    extra = {"scene_build_s": round(t_scene, 2), "rtx_create_s": round(t_create, 2),
+             "kernel_ms_per_frame": {"primary": kernel_ms[0], "shade0": kernel_ms[1], "trace1": kernel_ms[2],
+                                     "shade1": kernel_ms[3], "trace2": kernel_ms[4], "shade2": kernel_ms[5],
+                                     "trace3": kernel_ms[6], "shade3": kernel_ms[7]},
+             "device_ms_per_frame": c.totalMs / max(1, c.frames),
+             "rays_per_bounce_rank0": rays_per_bounce, "hits_per_bounce_rank0": hits_per_bounce}
+
+    if args.d2h and rank == 0:
+        px = np.zeros((H, W, 4), dtype=np.float32)
+        shader.Render(px, cam)
+        t1 = time.perf_counter()
+        for i in range(args.steps):
+            shader.frame_counter = args.warmup + args.steps + i
+            shader.Render(px, cam)
+        extra["ms_per_frame_with_d2h"] = (time.perf_counter() - t1) / args.steps * 1e3
+
+    # ---- roofline of the dominant kernel (rank 0): counted visits x record bytes / event time ----
+    roofline = None
+    if rank == 0:
+        shader.close()
+        counter = HIPShader(scene, device=local_rank, rank=rank, world_size=world, traversal=trav, count_stats=True)
+        for i in range(args.steps):
+            if args.orbit:
+                orbit_camera(cam, 0.1 * (args.warmup + i), 0.1 * (args.warmup + i))
+                counter.frame_counter = 0
+            else:
+                counter.frame_counter = args.warmup + i
+            counter.Render(None, cam)
+        cc = counter.counters()
+        counter.close()
+        trace_ms = [kernel_ms[0], kernel_ms[2], kernel_ms[4], kernel_ms[6]]
+        b = int(np.argmax(trace_ms))
+        inner = cc.innerVisits[b] / args.steps
+        leaf = cc.leafTests[b] / args.steps
+        algo_bytes = 64.0 * inner + 48.0 * leaf        # 64 B / inner visit, 48 B / leaf test
+        achieved = algo_bytes / (trace_ms[b] * 1e-3) / 1e9 if trace_ms[b] > 0 else 0.0
+        traffic = None
+        pmc = os.path.join(HERE, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get(args.workload, {}).get(["k_primary", "k_trace1", "k_trace2", "k_trace3"][b])
+            except Exception:
+                traffic = None
+        all_rays = sum(cc.raysPerBounce)
+        roofline = {"bound": "hbm", "kernel": ["k_primary", "k_trace(bounce1)", "k_trace(bounce2)", "k_trace(bounce3)"][b],
+                    "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                    "traffic": traffic,
+                    "algorithmic_bytes_per_launch": algo_bytes, "launch_ms": trace_ms[b],
+                    "inner_visits_per_ray": [cc.innerVisits[i] / max(1, cc.raysPerBounce[i]) for i in range(4)],
+                    "leaf_tests_per_ray": [cc.leafTests[i] / max(1, cc.raysPerBounce[i]) for i in range(4)],
+                    "algorithmic_bytes_per_ray_all_trace": (64.0 * sum(cc.innerVisits) + 48.0 * sum(cc.leafTests)) / max(1, all_rays)}
+
+    # ---- CPU baseline: the oracle (CPU restatement of ThreadedShader) on a bounded sample ----
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        import oracle
+        desc = scene.desc()
+        fc = args.warmup
+        px = np.zeros((H, W, 4), dtype=np.float32)
+        mid = H // 2
+        t1 = time.perf_counter()
+        st = oracle.render(desc, cam, fc, px, nthreads=cores, rows=(mid - 4, mid + 4), stats=1)
+        probe = time.perf_counter() - t1
+        rows = int(max(8, min(H, 8 * args.cpu_seconds / max(probe, 1e-3))))
+        y0 = max(0, mid - rows // 2)
+        t1 = time.perf_counter()
+        st = oracle.render(desc, cam, fc, px, nthreads=cores, rows=(y0, y0 + rows), stats=1)
+        dt = time.perf_counter() - t1
+        cpu = {"value": st.rays / dt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
+               "sample": f"rows {y0}..{y0 + rows} of {H} ({rows * W} pixels, {st.rays} rays) of frame {fc} of the same scene, "
+                         f"oracle/liboracle.so (strict -O2 restatement of ThreadedShader), {dt:.1f} s"}
+
+    if rank == 0:
+        out = {"metric": "Mrays/s", "value": rays / elapsed / 1e6, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
+               "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+               "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": args.workload, "triangles": ntri, "resolution": [W, H], "bounces": 4,
+                          "spp_per_step": 1, "traversal": args.traversal, "partition": f"tiles64x32 round-robin x{world}",
+                          "camera": "orbit" if args.orbit else "fixed"},
+               "roofline": roofline, "cpu_baseline": cpu, "extra": extra}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -138,16 +138,19 @@ typedef struct RtxConfig {
 } RtxConfig;
 
 typedef struct RtxCounters {
-    uint64_t frames;          /* rtx_render* calls since create / reset                    */
+    uint64_t frames;          /* rtx_render calls since create / reset                     */
     uint64_t rays;            /* closest-hit queries issued (primary + bounce)             */
     uint64_t raysPerBounce[4];
     uint64_t hitsPerBounce[4];
-    uint64_t innerVisits;     /* inner-node records fetched   (countStats only)            */
-    uint64_t leafTests;       /* leaf primitives intersected  (countStats only)            */
-    double   lastFrameMs;     /* device time of the last rtx_render* call (HIP events)     */
+    uint64_t innerVisits[4];  /* inner-node records fetched, per bounce (countStats only)  */
+    uint64_t leafTests[4];    /* leaf primitives intersected, per bounce (countStats only) */
+    double   lastFrameMs;     /* device time of the last rtx_render call (HIP events)      */
     double   lastTraceMs;     /* ... of which traversal kernels                            */
     double   lastShadeMs;     /* ... of which shading kernels                              */
-    double   totalMs;         /* sum of lastFrameMs                                        */
+    double   totalMs;         /* sum of lastFrameMs over `frames`                          */
+    /* per launch of the frame pipeline, summed over `frames` (HIP events on the
+     * renderer's stream): [0] primary, [1] shade0, [2] trace1, [3] shade1, ... [7] shade3 */
+    double   kernelMs[8];
 } RtxCounters;
 
 typedef struct RtxRenderer RtxRenderer;

@@ -71,6 +71,9 @@ int rtxh_scene_add_heightfield(RtxHostScene* s, uint64_t ntri, uint32_t seed,
  * nodes in pre-order, left subtree first), built in place and in parallel. */
 int rtxh_scene_build_bvh(RtxHostScene* s, int nthreads);
 
+/* Deep copy of caller-owned arrays (reference layouts) into a new scene. */
+RtxHostScene* rtxh_scene_from_arrays(const RtxSceneDesc* arrays, const RtxCamera* camera, uint32_t depth);
+
 /* Borrowed view for rtx_create(); valid until the scene is modified or freed. */
 int rtxh_scene_desc(RtxHostScene* s, RtxSceneDesc* out);
 int rtxh_scene_camera(RtxHostScene* s, RtxCamera* out);

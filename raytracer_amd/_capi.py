@@ -41,9 +41,9 @@ class Config(C.Structure):
 class Counters(C.Structure):
     _fields_ = [("frames", C.c_uint64), ("rays", C.c_uint64),
                 ("raysPerBounce", C.c_uint64 * 4), ("hitsPerBounce", C.c_uint64 * 4),
-                ("innerVisits", C.c_uint64), ("leafTests", C.c_uint64),
+                ("innerVisits", C.c_uint64 * 4), ("leafTests", C.c_uint64 * 4),
                 ("lastFrameMs", C.c_double), ("lastTraceMs", C.c_double), ("lastShadeMs", C.c_double),
-                ("totalMs", C.c_double)]
+                ("totalMs", C.c_double), ("kernelMs", C.c_double * 8)]
 
 
 # numpy mirrors of the reference PODs (sizes/offsets as in include/rtx.h)
@@ -114,6 +114,8 @@ def host_lib():
         L.rtxh_camera_look_at.restype = None
         L.rtxh_camera_orbit.argtypes = [C.POINTER(Camera), C.c_float, C.c_float, C.c_float]
         L.rtxh_camera_orbit.restype = None
+        L.rtxh_scene_from_arrays.restype = C.c_void_p
+        L.rtxh_scene_from_arrays.argtypes = [C.POINTER(SceneDesc), C.POINTER(Camera), C.c_uint32]
         L.rtxh_scene_load_blob.restype = C.c_void_p
         L.rtxh_scene_load_blob.argtypes = [C.c_char_p]
         L.rtxh_last_error.restype = C.c_char_p
@@ -161,6 +163,6 @@ EXPORTED_HIP = ["rtx_create", "rtx_render", "rtx_primary_hits", "rtx_trace_rays"
 EXPORTED_HOST = ["rtxh_scene_new", "rtxh_scene_free", "rtxh_scene_set_resolution", "rtxh_scene_load_scn", "rtxh_scene_load_mtl",
                  "rtxh_scene_load_obj", "rtxh_scene_material_id", "rtxh_scene_add_texture", "rtxh_scene_add_material",
                  "rtxh_scene_add_plane", "rtxh_scene_add_disk", "rtxh_scene_add_cube", "rtxh_scene_add_sphere",
-                 "rtxh_scene_add_mesh", "rtxh_scene_add_heightfield", "rtxh_scene_build_bvh", "rtxh_scene_desc",
+                 "rtxh_scene_add_mesh", "rtxh_scene_add_heightfield", "rtxh_scene_build_bvh", "rtxh_scene_from_arrays", "rtxh_scene_desc",
                  "rtxh_scene_camera", "rtxh_scene_set_camera", "rtxh_camera_look_at", "rtxh_camera_orbit",
                  "rtxh_scene_save_blob", "rtxh_scene_load_blob", "rtxh_last_error"]

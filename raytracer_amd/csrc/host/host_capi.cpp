@@ -114,6 +114,19 @@ int rtxh_scene_desc(RtxHostScene* h, RtxSceneDesc* out) {
     out->useBVH = s.bvhBuilt ? 1 : 0;
     return 0;
 }
+RtxHostScene* rtxh_scene_from_arrays(const RtxSceneDesc* d, const RtxCamera* cam, uint32_t depth) {
+    RtxHostScene* h = new RtxHostScene();
+    HostScene& s = h->s;
+    s.width = d->width; s.height = d->height; s.depth = depth; s.bvhBuilt = d->useBVH != 0;
+    s.camera = *cam;
+    s.objects.assign(d->objects, d->objects + d->numObjects);
+    s.materials.assign(d->materials, d->materials + d->numMaterials);
+    if (d->numBoxes) s.boxes.assign(d->boxes, d->boxes + d->numBoxes);
+    s.textureInfo.assign(d->textureInfo, d->textureInfo + d->numTextures);
+    s.textureData.assign(d->textureData, d->textureData + d->numTexels);
+    return h;
+}
+
 int rtxh_scene_camera(RtxHostScene* h, RtxCamera* out) { *out = h->s.camera; return 0; }
 int rtxh_scene_set_camera(RtxHostScene* h, const RtxCamera* in) { h->s.camera = *in; return 0; }
 

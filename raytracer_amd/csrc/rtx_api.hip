@@ -210,6 +210,7 @@ void finish_timing(RtxRenderer* r, int slot) {
     // kernel k (0..7) runs between events k and k+1: even = trace (primary, trace), odd = shade
     for (int k = 0; k < 8; ++k) {
         hipEventElapsedTime(&ms, r->ev[slot][k], r->ev[slot][k + 1]);
+        r->totals.kernelMs[k] += ms;
         if (k & 1) shade += ms; else trace += ms;
     }
     r->totals.lastFrameMs = total; r->totals.lastTraceMs = trace; r->totals.lastShadeMs = shade;
@@ -549,7 +550,7 @@ int rtx_get_counters(RtxRenderer* r, RtxCounters* out) {
     RtxCounters c = r->totals;
     c.rays = 0;
     for (int b = 0; b < 4; ++b) { c.raysPerBounce[b] = st[RTX_STAT_RAYS(b)]; c.hitsPerBounce[b] = st[RTX_STAT_HITS(b)]; c.rays += st[RTX_STAT_RAYS(b)]; }
-    c.innerVisits = st[RTX_STAT_INNER]; c.leafTests = st[RTX_STAT_LEAF];
+    for (int b = 0; b < 4; ++b) { c.innerVisits[b] = st[RTX_STAT_INNER(b)]; c.leafTests[b] = st[RTX_STAT_LEAF(b)]; }
     *out = c;
     return 0;
 }

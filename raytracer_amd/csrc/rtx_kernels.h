@@ -28,10 +28,10 @@
 #define RTX_CTRL_WORK(k) (8 + (k))
 #define RTX_CTRL_WORDS 32
 // stats[] layout (uint64)
-#define RTX_STAT_INNER 0
-#define RTX_STAT_LEAF 1
-#define RTX_STAT_RAYS(b) (2 + (b))
-#define RTX_STAT_HITS(b) (6 + (b))
+#define RTX_STAT_INNER(b) (b)
+#define RTX_STAT_LEAF(b) (4 + (b))
+#define RTX_STAT_RAYS(b) (8 + (b))
+#define RTX_STAT_HITS(b) (12 + (b))
 #define RTX_STAT_WORDS 16
 
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
@@ -90,6 +90,7 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_primary(DevScene sc, DevFrame fr,
     extern __shared__ int lds[];
     int* stack = lds + threadIdx.x;
     uint32_t ic = 0, lc = 0;
+    const int countIdx = 0;
     for (;;) {
         const uint32_t base = next_chunk(&ctrl[RTX_CTRL_WORK(workIdx)]);
         if (base >= (uint32_t)fr.numSlots) break;
@@ -110,7 +111,7 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_primary(DevScene sc, DevFrame fr,
     }
     if (COUNT) {
         ic = wave_sum(ic); lc = wave_sum(lc);
-        if ((threadIdx.x & 63) == 0) { atomicAdd(&stats[RTX_STAT_INNER], (unsigned long long)ic); atomicAdd(&stats[RTX_STAT_LEAF], (unsigned long long)lc); }
+        if ((threadIdx.x & 63) == 0) { atomicAdd(&stats[RTX_STAT_INNER(countIdx)], (unsigned long long)ic); atomicAdd(&stats[RTX_STAT_LEAF(countIdx)], (unsigned long long)lc); }
     }
 }
 
@@ -136,7 +137,7 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_trace(DevScene sc, const float4* 
     }
     if (COUNT) {
         ic = wave_sum(ic); lc = wave_sum(lc);
-        if ((threadIdx.x & 63) == 0) { atomicAdd(&stats[RTX_STAT_INNER], (unsigned long long)ic); atomicAdd(&stats[RTX_STAT_LEAF], (unsigned long long)lc); }
+        if ((threadIdx.x & 63) == 0) { atomicAdd(&stats[RTX_STAT_INNER(countIdx)], (unsigned long long)ic); atomicAdd(&stats[RTX_STAT_LEAF(countIdx)], (unsigned long long)lc); }
     }
 }
 

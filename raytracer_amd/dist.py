@@ -1,0 +1,92 @@
+"""Multi-GPU frame assembly: screen tiles are dealt round-robin to ranks
+(tile t -> rank t % world_size, scene replicated, seeds use the global pixel
+index so the partition never changes a pixel's value) and the finished tiles are
+gathered to rank 0 with one torch.distributed gather (RCCL over xGMI on GPUs).
+
+No reference counterpart: the reference renders on one device.
+The only collective on the path is this gather; rendering itself needs none.
+"""
+import numpy as np
+
+
+def tile_origins(width, height, tile_w=64, tile_h=32):
+    tx = (width + tile_w - 1) // tile_w
+    ty = (height + tile_h - 1) // tile_h
+    return [((t % tx) * tile_w, (t // tx) * tile_h) for t in range(tx * ty)]
+
+
+def tiles_of_rank(width, height, rank, world_size, tile_w=64, tile_h=32):
+    """Same rule as rtx_create (raytracer_amd/csrc/rtx_api.hip)."""
+    return [o for t, o in enumerate(tile_origins(width, height, tile_w, tile_h)) if t % world_size == rank]
+
+
+def pack_tiles_host(frame, tiles, tile_w=64, tile_h=32):
+    """Host mirror of rtx_pack_tiles: frame (h, w, 4) -> (len(tiles), tile_h, tile_w, 4)."""
+    h, w, _ = frame.shape
+    out = np.zeros((len(tiles), tile_h, tile_w, 4), dtype=frame.dtype)
+    for k, (x0, y0) in enumerate(tiles):
+        ww, hh = min(tile_w, w - x0), min(tile_h, h - y0)
+        out[k, :hh, :ww] = frame[y0:y0 + hh, x0:x0 + ww]
+    return out
+
+
+def unpack_tiles_host(frame, packed, tiles, tile_w=64, tile_h=32):
+    """Host mirror of rtx_unpack_tiles."""
+    h, w, _ = frame.shape
+    for k, (x0, y0) in enumerate(tiles):
+        ww, hh = min(tile_w, w - x0), min(tile_h, h - y0)
+        frame[y0:y0 + hh, x0:x0 + ww] = packed[k, :hh, :ww]
+    return frame
+
+
+def max_packed_floats(width, height, world_size, tile_w=64, tile_h=32):
+    n = len(tile_origins(width, height, tile_w, tile_h))
+    return ((n + world_size - 1) // world_size) * tile_w * tile_h * 4
+
+
+def gather_frame_host(frame, rank, world_size, tile=(64, 32), group=None):
+    """CPU / gloo variant (used by the tests): every rank passes its full-size
+    frame array in which only its own tiles are meaningful; rank 0 returns the
+    assembled frame, the others None."""
+    import torch
+    import torch.distributed as dist
+    h, w, _ = frame.shape
+    n = max_packed_floats(w, h, world_size, *tile)
+    mine = tiles_of_rank(w, h, rank, world_size, *tile)
+    send = torch.zeros(n, dtype=torch.float32)
+    p = pack_tiles_host(frame, mine, *tile).reshape(-1)
+    send[:p.size] = torch.from_numpy(np.ascontiguousarray(p))
+    bufs = [torch.zeros(n, dtype=torch.float32) for _ in range(world_size)] if rank == 0 else None
+    dist.gather(send, bufs, dst=0, group=group)
+    if rank != 0:
+        return None
+    out = np.array(frame, copy=True)
+    for src in range(world_size):
+        tiles = tiles_of_rank(w, h, src, world_size, *tile)
+        k = len(tiles) * tile[0] * tile[1] * 4
+        unpack_tiles_host(out, bufs[src][:k].numpy().reshape(len(tiles), tile[1], tile[0], 4), tiles, *tile)
+    return out
+
+
+class DeviceGather:
+    """GPU variant: packs this rank's tiles with rtx_pack_tiles into a torch CUDA
+    tensor, gathers over the process group (backend "nccl" = RCCL), and on rank 0
+    scatters every rank's tiles into the resident framebuffer with
+    rtx_unpack_tiles. Buffers are allocated once."""
+
+    def __init__(self, shader, rank, world_size, device, group=None):
+        import torch
+        self.shader, self.rank, self.world, self.group = shader, rank, world_size, group
+        n = max(shader.packed_floats(r) for r in range(world_size))
+        self.send = torch.zeros(n, dtype=torch.float32, device=device)
+        self.recv = [torch.zeros(n, dtype=torch.float32, device=device) for _ in range(world_size)] if rank == 0 else None
+
+    def gather(self):
+        import torch
+        import torch.distributed as dist
+        self.shader.pack_tiles(self.send.data_ptr())          # synchronises the renderer's stream
+        dist.gather(self.send, self.recv, dst=0, group=self.group)
+        if self.rank == 0:
+            torch.cuda.current_stream().synchronize()
+            for src in range(1, self.world):
+                self.shader.unpack_tiles(self.recv[src].data_ptr(), src)

@@ -170,6 +170,46 @@ class HostScene:
         return cls(_handle=h)
 
 
+def scene_from_arrays(width, height, objects, materials, boxes, texture_info, texture_data, camera, use_bvh=True, depth=480):
+    """New HostScene holding copies of numpy arrays in the reference layouts."""
+    arrs = [np.ascontiguousarray(objects, dtype=_capi.OBJECT), np.ascontiguousarray(materials, dtype=_capi.MATERIAL),
+            np.ascontiguousarray(boxes, dtype=_capi.BOX), np.ascontiguousarray(texture_info, dtype=_capi.TEXTURE),
+            np.ascontiguousarray(texture_data, dtype=np.uint32)]
+    d = SceneDesc()
+    d.objects, d.numObjects = arrs[0].ctypes.data, len(arrs[0])
+    d.materials, d.numMaterials = arrs[1].ctypes.data, len(arrs[1])
+    d.boxes, d.numBoxes = (arrs[2].ctypes.data if len(arrs[2]) else None), len(arrs[2])
+    d.textureInfo, d.numTextures = arrs[3].ctypes.data, len(arrs[3])
+    d.textureData, d.numTexels = arrs[4].ctypes.data, len(arrs[4])
+    d.width, d.height, d.useBVH = int(width), int(height), 1 if (use_bvh and len(arrs[2])) else 0
+    L = _capi.host_lib()
+    h = L.rtxh_scene_from_arrays(C.byref(d), C.byref(camera), depth)
+    return HostScene(_handle=h)
+
+
+def shrink_textures(scene, size=64):
+    """Copy of `scene` whose textures are box-filtered down to at most size x size
+    (integer arithmetic); used to keep committed fixtures small."""
+    info = np.array(scene.texture_info, copy=True)
+    data = scene.texture_data
+    new_data, new_info = [], np.array(info, copy=True)
+    off = 0
+    for i, t in enumerate(info):
+        w, h, o = int(t["width"]), int(t["height"]), int(t["offset"])
+        tex = data[o:o + w * h].reshape(h, w)
+        if w > size or h > size:
+            fx, fy = w // size, h // size
+            ch = [((tex >> (8 * k)) & 0xFF).astype(np.uint32)[:fy * size, :fx * size].reshape(size, fy, size, fx).sum(axis=(1, 3)) // (fx * fy)
+                  for k in range(3)]
+            tex = (ch[0] | (ch[1] << 8) | (ch[2] << 16) | np.uint32(255 << 24)).astype(np.uint32)
+            w = h = size
+        new_info[i]["width"], new_info[i]["height"], new_info[i]["offset"] = w, h, off
+        new_data.append(np.ascontiguousarray(tex).reshape(-1))
+        off += w * h
+    return scene_from_arrays(scene.width, scene.height, scene.objects, scene.materials, scene.boxes, new_info,
+                             np.concatenate(new_data), scene.camera, use_bvh=len(scene.boxes) > 0)
+
+
 def look_at(cam, target):
     _capi.host_lib().rtxh_camera_look_at(C.byref(cam), _f3(target))
     return cam

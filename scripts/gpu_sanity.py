@@ -31,5 +31,5 @@ for trav in (_capi.TRAVERSE_CULLED, _capi.TRAVERSE_EXACT):
         diff = np.abs(px - opx)
         print("frame", f, "maxabs", float(diff.max()), "psnr", psnr(px, opx), "exact_px", float((diff.max(axis=2) == 0).mean()), flush=True)
     c = r.counters()
-    print("rays", c.rays, list(c.raysPerBounce), list(c.hitsPerBounce), "inner", c.innerVisits, "leaf", c.leafTests, "ms", c.lastFrameMs, c.lastTraceMs, c.lastShadeMs, flush=True)
+    print("rays", c.rays, list(c.raysPerBounce), list(c.hitsPerBounce), "inner", list(c.innerVisits), "leaf", list(c.leafTests), "kms", [round(x,3) for x in c.kernelMs], "ms", c.lastFrameMs, c.lastTraceMs, c.lastShadeMs, flush=True)
     r.close()

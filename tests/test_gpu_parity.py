@@ -1,0 +1,206 @@
+"""Parity of the HIP backend (through the C-ABI in include/rtx.h) with the oracle
+and the committed golden fixtures. Bars (BASELINE.json north_star):
+  * primary-hit object ids: bit-exact;
+  * framebuffer: max-abs error <= MAX_ABS and PSNR >= 50 dB at equal spp.
+    (Measured: the framebuffers come out bit-identical; the tolerance is kept
+    because the double-precision libm calls in the shading terms are not pinned
+    bit for bit between glibc and the device libm.)"""
+import numpy as np
+import pytest
+
+import oracle
+from conftest import golden, psnr
+from raytracer_amd import _capi
+from raytracer_amd.renderer import HIPShader
+
+pytestmark = pytest.mark.gpu
+MAX_ABS = 2e-3
+MIN_PSNR = 50.0
+
+
+def check_fb(got, want):
+    assert not np.isnan(got).any()
+    assert float(np.abs(got - want).max()) <= MAX_ABS
+    assert psnr(got, want) >= MIN_PSNR
+
+
+@pytest.mark.parametrize("name", ["scene1", "scene2"])
+@pytest.mark.parametrize("traversal", [_capi.TRAVERSE_CULLED, _capi.TRAVERSE_EXACT])
+def test_golden_scene(name, traversal, request):
+    s = request.getfixturevalue(name)
+    r = HIPShader(s, traversal=traversal)
+    ids = r.primary_hits(0)
+    assert (ids == golden(name + "_ids_f0.npy")).all()
+    px = np.zeros((r.height, r.width, 4), np.float32)
+    for f in range(4):
+        r.frame_counter = f
+        r.Render(px)
+        if f == 0:
+            check_fb(px, golden(name + "_fb_f1.npy"))
+    check_fb(px, golden(name + "_fb_f4.npy"))
+    assert (r.download() == px).all()
+    r.close()
+
+
+def test_linear_traversal_matches_oracle(scene1):
+    from raytracer_amd.scene import scene_from_arrays
+    s = scene_from_arrays(scene1.width, scene1.height, scene1.objects, scene1.materials, scene1.boxes[:0],
+                          scene1.texture_info, scene1.texture_data, scene1.camera, use_bvh=False)
+    d, cam = s.desc(), s.camera
+    assert d.useBVH == 0
+    r = HIPShader(s)
+    assert (r.primary_hits(2) == oracle.primary_hits(d, cam, 2)).all()
+    px = np.zeros((d.height, d.width, 4), np.float32); want = np.zeros_like(px)
+    for f in range(2):
+        r.frame_counter = f
+        r.Render(px)
+        oracle.render(d, cam, f, want, 8)
+    check_fb(px, want)
+    r.close()
+
+
+def test_synthetic_scene_ids_fb_and_ray_counts(synth_small):
+    s = synth_small
+    d, cam = s.desc(), s.camera
+    r = HIPShader(s, count_stats=True)
+    for fc in (0, 1, 77):
+        assert (r.primary_hits(fc) == oracle.primary_hits(d, cam, fc)).all()
+    r.reset_counters()
+    px = np.zeros((d.height, d.width, 4), np.float32); want = np.zeros_like(px)
+    rays = [0, 0, 0, 0]; hits = [0, 0, 0, 0]
+    for f in range(3):
+        r.frame_counter = f
+        r.Render(px)
+        st = oracle.render(d, cam, f, want, 8, stats=1)
+        rays = [a + b for a, b in zip(rays, st.raysPerBounce)]
+        hits = [a + b for a, b in zip(hits, st.hitsPerBounce)]
+    check_fb(px, want)
+    c = r.counters()
+    assert list(c.raysPerBounce) == rays and list(c.hitsPerBounce) == hits and c.rays == sum(rays)
+    assert c.frames == 3 and sum(c.innerVisits) > 0 and sum(c.leafTests) > 0
+    r.close()
+
+
+def test_culled_and_exact_traversal_agree_on_incoherent_rays(synth_small):
+    s = synth_small
+    d = s.desc()
+    rng = np.random.default_rng(5)
+    n = 200_000
+    o = np.zeros((n, 4), np.float32); dirs = np.zeros((n, 4), np.float32)
+    o[:, :3] = rng.uniform([-400, 0, -600], [1400, 1200, 700], size=(n, 3))
+    v = rng.normal(size=(n, 3)); dirs[:, :3] = v / np.linalg.norm(v, axis=1, keepdims=True)
+    # axis-parallel rays: zero direction components exercise the 0*inf slab path
+    dirs[:1000, :3] = 0; dirs[:1000, 2] = 1
+    dirs[1000:2000, 0] = 0
+    v2 = dirs[1000:2000, :3]; dirs[1000:2000, :3] = v2 / np.linalg.norm(v2, axis=1, keepdims=True)
+    want_ids, want_pts, want_nrm = oracle.trace_rays(d, o, dirs)
+    for trav in (_capi.TRAVERSE_CULLED, _capi.TRAVERSE_EXACT):
+        r = HIPShader(s, traversal=trav)
+        ids, pts, nrm = r.trace_rays(o, dirs)
+        assert (ids == want_ids).all()
+        hit = ids >= 0
+        assert hit.sum() > 10_000
+        assert (pts[hit, :3].view(np.uint32) == want_pts[hit, :3].view(np.uint32)).all()
+        assert (nrm[hit, :3].view(np.uint32) == want_nrm[hit, :3].view(np.uint32)).all()
+        r.close()
+
+
+def test_running_mean_persists_and_resets(scene2):
+    """pixels is a read-modify-write accumulator (src/ThreadedShader.cpp:179-180); frameCounter = 0
+    makes the Lerp scale 1 (camera moves reset it, src/Main.cpp:75,103)."""
+    d, cam = scene2.desc(), scene2.camera
+    r = HIPShader(scene2)
+    px = np.zeros((d.height, d.width, 4), np.float32); want = np.zeros_like(px)
+    for fc in (0, 1, 2, 0, 1):
+        r.frame_counter = fc
+        r.Render(px)
+        oracle.render(d, cam, fc, want, 8)
+        check_fb(px, want)
+    start = np.random.default_rng(1).random(px.shape, dtype=np.float32)
+    r.upload(start); want = start.copy()
+    r.frame_counter = 3
+    r.Render(px); oracle.render(d, cam, 3, want, 8)
+    check_fb(px, want)
+    r.clear()
+    assert (r.download() == 0).all()
+    r.close()
+
+
+def test_moving_camera(scene1):
+    from raytracer_amd.scene import orbit
+    d = scene1.desc()
+    r = HIPShader(scene1)
+    cam = scene1.camera
+    px = np.zeros((d.height, d.width, 4), np.float32)
+    for i in range(3):
+        orbit(cam, 40.0 * i + 10, 5.0 * i, radius=2500.0)
+        want = np.zeros_like(px)
+        r.frame_counter = 0
+        r.Render(px, cam)
+        oracle.render(d, cam, 0, want, 8)
+        check_fb(px, want)
+        assert (r.primary_hits(0, cam) == oracle.primary_hits(d, cam, 0)).all()
+    r.close()
+
+
+def test_tile_partition_assembles_the_single_gpu_frame(scene2):
+    """world_size = 3 on one device: each rank renders only its tiles; packing and
+    unpacking them into rank 0's framebuffer reproduces the 1-rank frame."""
+    import ctypes as C
+    import torch
+    d = scene2.desc()
+    single = HIPShader(scene2)
+    full = np.zeros((d.height, d.width, 4), np.float32)
+    for f in range(2):
+        single.frame_counter = f
+        single.Render(full)
+    single.close()
+    ranks = [HIPShader(scene2, rank=k, world_size=3, tile=(32, 16)) for k in range(3)]
+    assert sum(x.local_pixel_count() for x in ranks) == d.width * d.height
+    partial = np.full_like(full, -7.0)
+    for x in ranks:
+        for f in range(2):
+            x.frame_counter = f
+            x.Render(partial)               # writes only that rank's tiles
+    assert (partial == full).all()
+    for k in (1, 2):
+        buf = torch.zeros(int(ranks[k].packed_floats(k)), dtype=torch.float32, device="cuda")
+        ranks[k].pack_tiles(buf.data_ptr())
+        torch.cuda.synchronize()
+        ranks[0].unpack_tiles(buf.data_ptr(), k)
+    assert (ranks[0].download() == full).all()
+    for x in ranks:
+        x.close()
+
+
+def test_rejects_bad_input(scene1):
+    import ctypes as C
+    L = _capi.hip_lib()
+    d = scene1.desc()
+    objs = np.array(scene1.objects, copy=True)
+    objs["materialID"][3] = 999
+    d.objects = objs.ctypes.data
+    h = C.c_void_p()
+    assert L.rtx_create(C.byref(d), None, C.byref(h)) != 0
+    assert b"materialID" in L.rtx_last_error()
+    d = scene1.desc()
+    boxes = np.array(scene1.boxes, copy=True)
+    boxes["leftID"][0] = 0                      # cycle
+    d.boxes = boxes.ctypes.data
+    assert L.rtx_create(C.byref(d), None, C.byref(h)) != 0
+    cfg = _capi.Config(tileW=12, tileH=8)
+    d = scene1.desc()
+    assert L.rtx_create(C.byref(d), C.byref(cfg), C.byref(h)) != 0
+
+
+def test_empty_scene_renders_sky(libs):
+    from raytracer_amd.scene import HostScene, procedural_texture
+    s = HostScene(64, 64)
+    s.add_texture(procedural_texture(32, 9))
+    d, cam = s.desc(), s.camera
+    r = HIPShader(s)
+    px = np.zeros((d.height, d.width, 4), np.float32); want = np.zeros_like(px)
+    r.Render(px); oracle.render(d, cam, 0, want, 2)
+    check_fb(px, want)
+    assert (r.primary_hits(0) == -1).all()
+    r.close()
