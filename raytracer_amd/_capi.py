@@ -126,7 +126,7 @@ def host_lib():
 def hip_lib():
     global _hip
     if _hip is None:
-        L = _load("librtx_hip.so")
+        L = _load(os.environ.get("RTX_HIP_LIB", "librtx_hip.so"))
         L.rtx_create.argtypes = [C.POINTER(SceneDesc), C.POINTER(Config), C.POINTER(C.c_void_p)]
         L.rtx_render.argtypes = [C.c_void_p, C.POINTER(Camera), C.c_uint32, C.c_void_p]
         L.rtx_primary_hits.argtypes = [C.c_void_p, C.POINTER(Camera), C.c_uint32, C.c_void_p]

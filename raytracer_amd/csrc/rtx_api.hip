@@ -4,12 +4,14 @@
 // entry point that computes anything launches HIP kernels or fails.
 #include "../../include/rtx.h"
 #include "rtx_kernels.h"
+#include "rtx_build.h"
 
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -37,6 +39,8 @@ struct RtxRenderer {
 
     DevScene sc{};
     // device allocations
+    float4 *dFast = nullptr;
+    int2* dSpill = nullptr;
     float4 *dInner = nullptr, *dLeaf = nullptr, *dShade = nullptr, *dMaterials = nullptr;
     int4* dTexInfo = nullptr;
     uint32_t* dTexels = nullptr;
@@ -74,79 +78,130 @@ namespace {
 
 struct Flat {
     std::vector<float4> inner, leaf, shade;
-    int rootRef = 0;
-    int maxDepth = 0;
+    std::vector<rtxbuild::Node> fast;   // own SAH tree over the same leaves (empty: not built)
+    int rootRef = 0, fastRoot = 0;
+    int maxDepth = 0, fastDepth = 0;
+    bool nested = true;                 // every box contains its children (precondition of the own tree)
 };
 
 inline float i2f(int32_t v) { float f; memcpy(&f, &v, 4); return f; }
 
-void emit_leaf(const RtxObject& o, int32_t objectID, int32_t boxID, Flat& f) {
+void emit_leaf(const RtxObject& o, int32_t objectID, int32_t boxID, float4* leaf, float4* shade) {
     const RtxVec4 A = o.vertices[0], B = o.vertices[1], C = o.vertices[2];
-    float4 q0, q1, q2, q3;
     if (o.type == RTX_TRIANGLE) {
         // e1 = B - A, e2 = C - A: the same two subtractions the reference performs
         // first in IntersectTriangle (src/ThreadedShader.cpp:298-299)
         const float e1x = B.x - A.x, e1y = B.y - A.y, e1z = B.z - A.z;
         const float e2x = C.x - A.x, e2y = C.y - A.y, e2z = C.z - A.z;
-        q0 = make_float4(A.x, A.y, A.z, e1x);
-        q1 = make_float4(e1y, e1z, e2x, e2y);
-        q2 = make_float4(e2z, i2f(objectID), i2f(boxID), i2f(o.type));
-        q3 = make_float4(B.x, B.y, C.x, C.y);
+        leaf[0] = make_float4(A.x, A.y, A.z, e1x);
+        leaf[1] = make_float4(e1y, e1z, e2x, e2y);
+        leaf[2] = make_float4(e2z, i2f(objectID), i2f(boxID), i2f(o.type));
+        leaf[3] = make_float4(B.x, B.y, C.x, C.y);
     } else {
-        q0 = make_float4(o.position.x, o.position.y, o.position.z, o.radius);
-        q1 = make_float4(0, 0, 0, 0);
-        q2 = make_float4(0, i2f(objectID), i2f(boxID), i2f(o.type));
-        q3 = make_float4(0, 0, 0, 0);
+        leaf[0] = make_float4(o.position.x, o.position.y, o.position.z, o.radius);
+        leaf[1] = make_float4(0, 0, 0, 0);
+        leaf[2] = make_float4(0, i2f(objectID), i2f(boxID), i2f(o.type));
+        leaf[3] = make_float4(0, 0, 0, 0);
     }
-    f.leaf.push_back(q0); f.leaf.push_back(q1); f.leaf.push_back(q2); f.leaf.push_back(q3);
     const RtxVec4 n0 = o.normals[0], n1 = o.normals[1], n2 = o.normals[2];
-    f.shade.push_back(make_float4(n0.x, n0.y, n0.z, n1.x));
-    f.shade.push_back(make_float4(n1.y, n1.z, n2.x, n2.y));
-    f.shade.push_back(make_float4(n2.z, i2f(o.materialID), 0, 0));
+    shade[0] = make_float4(n0.x, n0.y, n0.z, n1.x);
+    shade[1] = make_float4(n1.y, n1.z, n2.x, n2.y);
+    shade[2] = make_float4(n2.z, i2f(o.materialID), 0, 0);
 }
 
 const int32_t kNoChild = (int32_t)0x80000000;   // never passes (see traverse_bvh)
 
-int flatten(const RtxSceneDesc& s, bool useBVH, Flat& f) {
+int flatten(const RtxSceneDesc& s, bool useBVH, bool wantFast, int nthreads, Flat& f) {
     const uint64_t nObj = s.numObjects, nBox = s.numBoxes;
     for (uint64_t i = 0; i < nObj; ++i) {
         const int32_t m = s.objects[i].materialID;
         if (m < 0 || (uint64_t)m >= s.numMaterials) return fail("object " + std::to_string(i) + ": materialID out of range");
     }
     if (!useBVH) {
-        f.leaf.reserve(nObj * 4); f.shade.reserve(nObj * 3);
-        for (uint64_t i = 0; i < nObj; ++i) emit_leaf(s.objects[i], (int32_t)i, (int32_t)i, f);
+        f.leaf.resize(nObj * 4); f.shade.resize(nObj * 3);
+        for (uint64_t i = 0; i < nObj; ++i) emit_leaf(s.objects[i], (int32_t)i, (int32_t)i, &f.leaf[i * 4], &f.shade[i * 3]);
         f.rootRef = 0; f.maxDepth = 0;
         return 0;
     }
     if (nBox > 0x7fffffffull) return fail("too many boxes");
     // index of every box inside its own array (inner / leaf), in box order
     std::vector<int32_t> slotOf(nBox);
+    std::vector<int32_t> leafBox;        // reference leaf index -> box index
     int32_t nInner = 0, nLeaf = 0;
     for (uint64_t b = 0; b < nBox; ++b) {
         const RtxBoundingBox& box = s.boxes[b];
         if (box.objectID != -1) {
             if (box.objectID < 0 || (uint64_t)box.objectID >= nObj) return fail("box " + std::to_string(b) + ": objectID out of range");
             slotOf[b] = nLeaf++;
+            leafBox.push_back((int32_t)b);
         } else {
             slotOf[b] = nInner++;
         }
     }
+    // depth + tree check (every box reached at most once) + nesting check (parent contains child)
+    {
+        std::vector<uint8_t> seen(nBox, 0);
+        std::vector<std::pair<int32_t, int32_t>> st;
+        st.emplace_back(0, 0);
+        int maxDepth = 0;
+        while (!st.empty()) {
+            auto [b, depth] = st.back(); st.pop_back();
+            if (seen[b]) return fail("boxes do not form a tree (box " + std::to_string(b) + " reached twice)");
+            seen[b] = 1;
+            maxDepth = std::max(maxDepth, depth);
+            const RtxBoundingBox& box = s.boxes[b];
+            if (box.objectID != -1) continue;
+            const int32_t child[2] = {box.leftID, box.rightID};
+            for (int k = 0; k < 2; ++k) {
+                if (child[k] == -1) continue;   // the reference guards children with != -1 (src/ThreadedShader.cpp:380,387)
+                if (child[k] < 0 || (uint64_t)child[k] >= nBox) return fail("box " + std::to_string(b) + ": child out of range");
+                const RtxBoundingBox& c = s.boxes[child[k]];
+                const bool in = box.minimalPosition.x <= c.minimalPosition.x && box.minimalPosition.y <= c.minimalPosition.y &&
+                                box.minimalPosition.z <= c.minimalPosition.z && box.maximalPosition.x >= c.maximalPosition.x &&
+                                box.maximalPosition.y >= c.maximalPosition.y && box.maximalPosition.z >= c.maximalPosition.z;
+                if (!in && b != 0) f.nested = false;     // the root's own box is never tested by the reference
+                st.emplace_back(child[k], depth + 1);
+            }
+        }
+        f.maxDepth = maxDepth;
+        for (uint64_t b = 0; b < nBox; ++b) if (!seen[b] && s.boxes[b].objectID != -1) f.nested = false;   // unreachable leaf: keep the reference topology
+    }
+    // own tree over the same leaf boxes (DESIGN.md "Topology freedom")
+    std::vector<uint32_t> order((size_t)nLeaf);
+    for (int32_t k = 0; k < nLeaf; ++k) order[k] = (uint32_t)k;
+    if (wantFast && f.nested && nLeaf >= 2) {
+        std::vector<rtxbuild::Box> prim((size_t)nLeaf);
+        for (int32_t k = 0; k < nLeaf; ++k) {
+            const RtxBoundingBox& b = s.boxes[leafBox[k]];
+            prim[k].lo[0] = b.minimalPosition.x; prim[k].lo[1] = b.minimalPosition.y; prim[k].lo[2] = b.minimalPosition.z;
+            prim[k].hi[0] = b.maximalPosition.x; prim[k].hi[1] = b.maximalPosition.y; prim[k].hi[2] = b.maximalPosition.z;
+        }
+        f.fast.resize((size_t)nLeaf - 1);
+        f.fastRoot = rtxbuild::build_sah(prim.data(), (uint32_t)nLeaf, order.data(), f.fast.data(), nthreads, f.fastDepth);
+        if (f.fastDepth > 60) { f.fast.clear(); for (int32_t k = 0; k < nLeaf; ++k) order[k] = (uint32_t)k; }
+    }
+    // leaves in the new order; reference leaf index -> position
+    std::vector<int32_t> posOf((size_t)nLeaf);
+    for (int32_t p = 0; p < nLeaf; ++p) posOf[order[p]] = p;
+    f.leaf.resize((size_t)nLeaf * 4); f.shade.resize((size_t)nLeaf * 3);
+    for (int32_t p = 0; p < nLeaf; ++p) {
+        const int32_t b = leafBox[order[p]];
+        emit_leaf(s.objects[s.boxes[b].objectID], s.boxes[b].objectID, b, &f.leaf[(size_t)p * 4], &f.shade[(size_t)p * 3]);
+    }
+    // the reference's own topology (used by RTX_TRAVERSE_EXACT and by lanes that cannot use the own tree)
     f.inner.assign((size_t)nInner * 4, make_float4(0, 0, 0, 0));
-    f.leaf.reserve((size_t)nLeaf * 4); f.shade.reserve((size_t)nLeaf * 3);
     for (uint64_t b = 0; b < nBox; ++b) {
         const RtxBoundingBox& box = s.boxes[b];
-        if (box.objectID != -1) { emit_leaf(s.objects[box.objectID], box.objectID, (int32_t)b, f); continue; }
+        if (box.objectID != -1) continue;
         float lo[2][3] = {{0, 0, 0}, {0, 0, 0}}, hi[2][3] = {{0, 0, 0}, {0, 0, 0}};
         int32_t ref[2] = {kNoChild, kNoChild};
         const int32_t child[2] = {box.leftID, box.rightID};
         for (int k = 0; k < 2; ++k) {
-            if (child[k] == -1) continue;     // the reference guards children with != -1 (src/ThreadedShader.cpp:380,387)
-            if (child[k] < 0 || (uint64_t)child[k] >= nBox) return fail("box " + std::to_string(b) + ": child out of range");
+            if (child[k] < 0 || (uint64_t)child[k] >= nBox) continue;
             const RtxBoundingBox& c = s.boxes[child[k]];
             lo[k][0] = c.minimalPosition.x; lo[k][1] = c.minimalPosition.y; lo[k][2] = c.minimalPosition.z;
             hi[k][0] = c.maximalPosition.x; hi[k][1] = c.maximalPosition.y; hi[k][2] = c.maximalPosition.z;
-            ref[k] = c.objectID != -1 ? ~slotOf[child[k]] : slotOf[child[k]];
+            ref[k] = c.objectID != -1 ? ~posOf[slotOf[child[k]]] : slotOf[child[k]];
         }
         float4* n = &f.inner[(size_t)slotOf[b] * 4];
         n[0] = make_float4(lo[0][0], lo[0][1], lo[0][2], hi[0][0]);
@@ -154,23 +209,7 @@ int flatten(const RtxSceneDesc& s, bool useBVH, Flat& f) {
         n[2] = make_float4(lo[1][2], hi[1][0], hi[1][1], hi[1][2]);
         n[3] = make_float4(i2f(ref[0]), i2f(ref[1]), 0, 0);
     }
-    f.rootRef = s.boxes[0].objectID != -1 ? ~slotOf[0] : slotOf[0];
-    // depth + tree check: every box may be reached at most once from the root
-    std::vector<uint8_t> seen(nBox, 0);
-    std::vector<std::pair<int32_t, int32_t>> st;
-    st.emplace_back(0, 0);
-    int maxDepth = 0;
-    while (!st.empty()) {
-        auto [b, depth] = st.back(); st.pop_back();
-        if (seen[b]) return fail("boxes do not form a tree (box " + std::to_string(b) + " reached twice)");
-        seen[b] = 1;
-        maxDepth = std::max(maxDepth, depth);
-        const RtxBoundingBox& box = s.boxes[b];
-        if (box.objectID != -1) continue;
-        if (box.leftID != -1) st.emplace_back(box.leftID, depth + 1);
-        if (box.rightID != -1) st.emplace_back(box.rightID, depth + 1);
-    }
-    f.maxDepth = maxDepth;
+    f.rootRef = s.boxes[0].objectID != -1 ? ~posOf[slotOf[0]] : slotOf[0];
     return 0;
 }
 
@@ -264,7 +303,7 @@ void rtx_destroy(RtxRenderer* r) {
     if (!r) return;
     hipSetDevice(r->device);
     if (r->stream) hipStreamSynchronize(r->stream);
-    void* ptrs[] = {r->dInner, r->dLeaf, r->dShade, r->dMaterials, r->dTexInfo, r->dTexels, r->dTiles, r->dRqO[0], r->dRqO[1],
+    void* ptrs[] = {r->dSpill, r->dFast, r->dInner, r->dLeaf, r->dShade, r->dMaterials, r->dTexInfo, r->dTexels, r->dTiles, r->dRqO[0], r->dRqO[1],
                     r->dRqD[0], r->dRqD[1], r->dHitT, r->dHitLeaf, r->dLight, r->dAcc, r->dFb, r->dSeeds, r->dCtrl, r->dStats};
     for (void* p : ptrs) if (p) hipFree(p);
     for (int2* p : r->dTilesOfRank) if (p) hipFree(p);
@@ -304,7 +343,8 @@ int rtx_create(const RtxSceneDesc* scene, const RtxConfig* cfgIn, RtxRenderer** 
     if (useBVH && !scene->boxes) return fail("boxes is NULL");
 
     Flat flat;
-    if (flatten(*scene, useBVH, flat)) return 1;
+    const bool wantFast = cfg.traversal != RTX_TRAVERSE_EXACT;
+    if (flatten(*scene, useBVH, wantFast, 16, flat)) return 1;
     if (useBVH && flat.maxDepth > 62) return fail("BVH deeper than 62 levels is not supported (the reference's own stack holds 32)");
 
     RtxRenderer* r = new RtxRenderer();
@@ -312,7 +352,8 @@ int rtx_create(const RtxSceneDesc* scene, const RtxConfig* cfgIn, RtxRenderer** 
     r->cfg = cfg; r->device = cfg.device;
     r->width = scene->width; r->height = scene->height;
     r->linear = !useBVH;
-    r->mode = r->linear ? RTX_MODE_LINEAR : (cfg.traversal == RTX_TRAVERSE_EXACT ? RTX_MODE_EXACT : RTX_MODE_CULLED);
+    // distance culling needs boxes that contain their descendants; otherwise keep the reference's visit set
+    r->mode = r->linear ? RTX_MODE_LINEAR : ((cfg.traversal == RTX_TRAVERSE_EXACT || !flat.nested) ? RTX_MODE_EXACT : RTX_MODE_CULLED);
     r->tileW = cfg.tileW; r->tileH = cfg.tileH;
 
 #define CREATE_TRY(expr) do { if (expr) { rtx_destroy(r); return 1; } } while (0)
@@ -349,6 +390,7 @@ int rtx_create(const RtxSceneDesc* scene, const RtxConfig* cfgIn, RtxRenderer** 
 
     // scene
     CREATE_TRY(upload(&r->dInner, flat.inner.data(), flat.inner.size() * sizeof(float4)));
+    if (!flat.fast.empty()) CREATE_TRY(upload(&r->dFast, flat.fast.data(), flat.fast.size() * sizeof(rtxbuild::Node)));
     CREATE_TRY(upload(&r->dLeaf, flat.leaf.data(), flat.leaf.size() * sizeof(float4)));
     CREATE_TRY(upload(&r->dShade, flat.shade.data(), flat.shade.size() * sizeof(float4)));
     CREATE_TRY(upload(&r->dMaterials, scene->materials, scene->numMaterials * sizeof(RtxMaterial)));
@@ -359,6 +401,8 @@ int rtx_create(const RtxSceneDesc* scene, const RtxConfig* cfgIn, RtxRenderer** 
     r->sc.texInfo = r->dTexInfo; r->sc.texels = r->dTexels;
     r->sc.numTexelsPadded = (long long)scene->numTexels + RTX_TEX_PAD;
     r->sc.rootRef = flat.rootRef;
+    r->sc.fast = r->dFast;            // NULL: the fast path walks the reference topology too
+    r->sc.fastRoot = flat.fastRoot;
     r->sc.numLeaves = (int)(flat.leaf.size() / 4);
     r->sc.numInner = (int)(flat.inner.size() / 4);
     r->sc.numMaterials = (int)scene->numMaterials;
@@ -367,7 +411,7 @@ int rtx_create(const RtxSceneDesc* scene, const RtxConfig* cfgIn, RtxRenderer** 
     // single texture the reference reads past the vector, here texture 0 is used
     r->sc.skyTex = scene->numTextures > 1 ? 1 : 0;
     r->sc.useBVH = useBVH ? 1 : 0;
-    r->sc.stackDepth = std::max(2, flat.maxDepth + 2);
+    r->sc.stackDepth = std::max(2, std::max(flat.maxDepth, flat.fast.empty() ? 0 : flat.fastDepth) + 2);
 
     // per-path state and queues
     const size_t n = std::max<size_t>(r->numSlots, 64);
@@ -388,12 +432,22 @@ int rtx_create(const RtxSceneDesc* scene, const RtxConfig* cfgIn, RtxRenderer** 
     CREATE_HIP(hipMemset(r->dFb, 0, fbBytes));      // zero-filled like src/WindowManager.cpp:26-27
 
     // launch geometry: persistent grids sized by the LDS the traversal stack needs
-    r->ldsTrace = r->linear ? 0 : (size_t)r->sc.stackDepth * RTX_BLOCK * sizeof(int);
+    // culled path: a fixed window of the stack in LDS; exact path: the whole stack (refs only)
+    r->ldsTrace = r->linear ? 0 : (r->mode == RTX_MODE_CULLED ? (size_t)2 * RTX_LDS_WINDOW : (size_t)r->sc.stackDepth) * RTX_BLOCK * sizeof(int);
+
     int blocksPerCU = 8;
     if (r->ldsTrace) blocksPerCU = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / r->ldsTrace));
     r->gridTrace = r->numCUs * blocksPerCU;
     r->gridShade = r->numCUs * 4;
+    if (r->mode == RTX_MODE_CULLED) {
+        CREATE_HIP(hipMalloc((void**)&r->dSpill, (size_t)r->sc.stackDepth * r->gridTrace * RTX_BLOCK * sizeof(int2)));
+        r->sc.spill = r->dSpill;
+    }
     CREATE_HIP(hipDeviceSynchronize());
+    if (getenv("RTX_VERBOSE"))
+        fprintf(stderr, "[rtx] %d leaves, reference tree depth %d, own tree %s depth %d, stack %d entries, LDS %zu B/block, %d blocks/CU x %d CUs, mode %d\n",
+                r->sc.numLeaves, flat.maxDepth, flat.fast.empty() ? "absent" : "built", flat.fastDepth, r->sc.stackDepth, r->ldsTrace,
+                blocksPerCU, r->numCUs, r->mode);
     *out = r;
     return 0;
 }

@@ -1,0 +1,135 @@
+// rtx_build.h — host-side construction of the traversal tree the fast path uses.
+//
+// The reference's closest-hit result does not depend on the tree's topology
+// (DESIGN.md "Topology freedom"): with boxes that contain their descendants, a
+// leaf is tested iff its OWN box passes the reference slab test, the winner is
+// the smallest t, ties go to the largest reference boxID. So rtx_create may
+// index the same leaves (same leaf boxes, same primitives) with a better tree
+// than the host's object-median one — whose few huge primitives (floor, light)
+// sit at the bottom of the left spine and bloat every box above them.
+//
+// Binned SAH, top-down, one primitive per leaf, boxes = exact min/max unions of
+// the given leaf boxes. A subtree over n leaves has n-1 inner nodes, so node and
+// leaf positions are known before a subtree is built: arrays are allocated
+// once and sibling subtrees are built on separate threads.
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+namespace rtxbuild {
+
+struct Box { float lo[3], hi[3]; };
+
+struct Node {           // one 64-byte inner record (layout of rtx_device.h)
+    float q[16];
+};
+
+inline void grow(Box& b, const Box& o) {
+    for (int a = 0; a < 3; ++a) { b.lo[a] = o.lo[a] < b.lo[a] ? o.lo[a] : b.lo[a]; b.hi[a] = o.hi[a] > b.hi[a] ? o.hi[a] : b.hi[a]; }
+}
+inline Box empty_box() { Box b; for (int a = 0; a < 3; ++a) { b.lo[a] = INFINITY; b.hi[a] = -INFINITY; } return b; }
+inline double half_area(const Box& b) {
+    double d0 = (double)b.hi[0] - b.lo[0], d1 = (double)b.hi[1] - b.lo[1], d2 = (double)b.hi[2] - b.lo[2];
+    if (!(d0 >= 0) || !(d1 >= 0) || !(d2 >= 0)) return 0.0;
+    return d0 * d1 + d1 * d2 + d2 * d0;
+}
+inline int32_t f2i(float f) { int32_t i; memcpy(&i, &f, 4); return i; }
+inline float i2f(int32_t i) { float f; memcpy(&f, &i, 4); return f; }
+
+struct SahBuilder {
+    const Box* prim;        // leaf boxes, indexed by primitive (= input leaf index)
+    uint32_t* order;        // permutation being partitioned in place; final = leaf order of the new tree
+    Node* nodes;            // n-1 inner records
+    int parallelDepth;
+    int maxDepth = 0;
+
+    static const int kBins = 16;
+
+    // builds the subtree over order[begin,end); returns its ref (>=0 inner index, <0 ~leafPosition)
+    int32_t build(uint32_t begin, uint32_t end, int32_t nodeIdx, int depth, Box& outBox, int& outDepth) {
+        const uint32_t n = end - begin;
+        if (n == 1) { outBox = prim[order[begin]]; outDepth = depth; return ~(int32_t)begin; }
+        // centroid bounds
+        float clo[3] = {INFINITY, INFINITY, INFINITY}, chi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (uint32_t i = begin; i < end; ++i) {
+            const Box& b = prim[order[i]];
+            for (int a = 0; a < 3; ++a) { float c = 0.5f * b.lo[a] + 0.5f * b.hi[a]; clo[a] = std::min(clo[a], c); chi[a] = std::max(chi[a], c); }
+        }
+        int bestAxis = -1, bestBin = -1; double bestCost = INFINITY;
+        for (int a = 0; a < 3; ++a) {
+            const float ext = chi[a] - clo[a];
+            if (!(ext > 0.0f) || !std::isfinite(ext)) continue;
+            Box bb[kBins]; uint32_t cnt[kBins];
+            for (int k = 0; k < kBins; ++k) { bb[k] = empty_box(); cnt[k] = 0; }
+            const float scale = (float)kBins / ext;
+            for (uint32_t i = begin; i < end; ++i) {
+                const Box& b = prim[order[i]];
+                int k = (int)((0.5f * b.lo[a] + 0.5f * b.hi[a] - clo[a]) * scale);
+                k = k < 0 ? 0 : (k >= kBins ? kBins - 1 : k);
+                grow(bb[k], b); cnt[k]++;
+            }
+            double rightArea[kBins]; uint32_t rightCnt[kBins];
+            Box acc = empty_box(); uint32_t c = 0;
+            for (int k = kBins - 1; k > 0; --k) { grow(acc, bb[k]); c += cnt[k]; rightArea[k] = half_area(acc); rightCnt[k] = c; }
+            acc = empty_box(); c = 0;
+            for (int k = 0; k < kBins - 1; ++k) {
+                grow(acc, bb[k]); c += cnt[k];
+                if (c == 0 || rightCnt[k + 1] == 0) continue;
+                double cost = half_area(acc) * c + rightArea[k + 1] * rightCnt[k + 1];
+                if (cost < bestCost) { bestCost = cost; bestAxis = a; bestBin = k; }
+            }
+        }
+        uint32_t mid;
+        if (bestAxis >= 0) {
+            const int a = bestAxis;
+            const float scale = (float)kBins / (chi[a] - clo[a]);
+            const float lo = clo[a];
+            uint32_t* m = std::partition(order + begin, order + end, [&](uint32_t p) {
+                const Box& b = prim[p];
+                int k = (int)((0.5f * b.lo[a] + 0.5f * b.hi[a] - lo) * scale);
+                k = k < 0 ? 0 : (k >= kBins ? kBins - 1 : k);
+                return k <= bestBin;
+            });
+            mid = (uint32_t)(m - order);
+            if (mid == begin || mid == end) mid = begin + n / 2;
+        } else {
+            mid = begin + n / 2;      // all centroids coincide (or are not finite): split by count
+        }
+        const uint32_t nl = mid - begin;
+        const int32_t leftIdx = nodeIdx + 1, rightIdx = nodeIdx + (int32_t)nl;   // left subtree has nl-1 inner nodes
+        Box bl, br; int dl = 0, dr = 0; int32_t rl, rr;
+        if (depth < parallelDepth && n > 8192) {
+            std::thread t([&]() { rl = build(begin, mid, leftIdx, depth + 1, bl, dl); });
+            rr = build(mid, end, rightIdx, depth + 1, br, dr);
+            t.join();
+        } else {
+            rl = build(begin, mid, leftIdx, depth + 1, bl, dl);
+            rr = build(mid, end, rightIdx, depth + 1, br, dr);
+        }
+        float* q = nodes[nodeIdx].q;
+        q[0] = bl.lo[0]; q[1] = bl.lo[1]; q[2] = bl.lo[2]; q[3] = bl.hi[0]; q[4] = bl.hi[1]; q[5] = bl.hi[2];
+        q[6] = br.lo[0]; q[7] = br.lo[1]; q[8] = br.lo[2]; q[9] = br.hi[0]; q[10] = br.hi[1]; q[11] = br.hi[2];
+        q[12] = i2f(rl); q[13] = i2f(rr); q[14] = 0; q[15] = 0;
+        outBox = bl; grow(outBox, br);
+        outDepth = std::max(dl, dr);
+        return nodeIdx;
+    }
+};
+
+// order[] in: any permutation of 0..n-1; out: leaf order of the new tree.
+// Returns the root ref; nodes must hold n-1 records.
+inline int32_t build_sah(const Box* prim, uint32_t n, uint32_t* order, Node* nodes, int nthreads, int& maxDepth) {
+    int par = 0;
+    while ((1 << par) < nthreads) ++par;
+    SahBuilder b{prim, order, nodes, par};
+    Box root; int depth = 0;
+    int32_t ref = b.build(0, n, 0, 0, root, depth);
+    maxDepth = depth;
+    return ref;
+}
+
+} // namespace rtxbuild

@@ -1,7 +1,8 @@
 // rtx_device.h — device-side data layout and arithmetic of the HIP backend.
 //
 // HBM layout (all arrays 64-byte aligned, read-only during a frame):
-//   inner[]   64 B / inner node : both children's AABBs + both child refs
+//   inner[]   64 B / inner node : the reference's topology (pre-order), both children's AABBs + both child refs
+//   fast[]    64 B / inner node : same leaves indexed by a binned-SAH tree built in rtx_create (rtx_build.h)
 //             q0 = (lo0.x lo0.y lo0.z hi0.x) q1 = (hi0.y hi0.z lo1.x lo1.y)
 //             q2 = (lo1.z hi1.x hi1.y hi1.z) q3 = (ref0 ref1 - -)      ref>=0 inner, ref<0 leaf ~ref
 //   leaf[]    64 B / primitive  : q0 = (A.x A.y A.z e1.x) q1 = (e1.y e1.z e2.x e2.y)
@@ -57,6 +58,8 @@ __device__ __forceinline__ float rtx_rand(uint32_t& seed) {
 }
 
 struct DevScene {
+    const float4* fast;   // own SAH tree over the same leaves (may be NULL); same record layout as inner[]
+    int fastRoot;
     const float4* inner;
     const float4* leaf;
     const float4* shade;
@@ -71,7 +74,8 @@ struct DevScene {
     int numTextures;
     int skyTex;
     int useBVH;
-    int stackDepth;     // LDS stack entries per lane
+    int stackDepth;     // stack entries a lane can need (tree depth + 2)
+    int2* spill;        // [stackDepth][threads of the trace grid]: stack entries below the LDS window
 };
 
 struct DevFrame {

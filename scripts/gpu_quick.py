@@ -1,0 +1,19 @@
+"""Quick timing of the 4K 10M-triangle workload (no CPU baseline, no counting pass)."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("RTX_VERBOSE", "1")
+import numpy as np
+from raytracer_amd.scene import synthetic_scene
+from raytracer_amd.renderer import HIPShader
+ntri = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
+s = synthetic_scene(ntri, 3840, 2160, nthreads=16)
+t = time.time(); r = HIPShader(s); print("create s", round(time.time() - t, 2), flush=True)
+for f in range(2):
+    r.frame_counter = f; r.Render(None)
+r.reset_counters()
+K = 6
+for f in range(K):
+    r.frame_counter = 2 + f; r.Render(None)
+c = r.counters()
+km = [round(x / K, 3) for x in c.kernelMs]
+print("ms/frame", round(c.totalMs / K, 3), "Mrays/s", round(c.rays / (c.totalMs * 1e-3) / 1e6, 1), "kernels", km, flush=True)
