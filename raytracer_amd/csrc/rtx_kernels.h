@@ -23,9 +23,10 @@
 #define RTX_MODE_LINEAR 2
 #define RTX_INVALID_SLOT (-2)
 
-// ctrl[] layout (uint32): [0..7] queue counts per bounce, [8..23] work counters per launch
+// ctrl[] layout (uint32): [0..7] queue counts per bounce, [8..23] work counters per launch, [24..27] slow-list lengths
 #define RTX_CTRL_COUNT(b) (b)
 #define RTX_CTRL_WORK(k) (8 + (k))
+#define RTX_CTRL_SLOW(b) (24 + (b))     // rays of bounce b handed to the reference-topology kernel
 #define RTX_CTRL_WORDS 32
 // stats[] layout (uint64)
 #define RTX_STAT_INNER(b) (b)
@@ -122,6 +123,28 @@ __device__ __forceinline__ void primary_ray(const DevFrame& fr, int x, int y, ui
     d = normalize4(sub4(p, o));
 }
 
+// Culled mode: ray generation is its own launch (it needs ~100 VGPRs for the double-precision
+// jitter arithmetic; the traversal kernel then keeps 8 waves per SIMD) and writes the bounce-0 queue
+// in slot order. rqD.w = 1 marks a slot outside the image.
+__global__ __launch_bounds__(RTX_BLOCK) void k_raygen(DevFrame fr, const int2* __restrict__ tiles,
+                                                      float4* __restrict__ rqO, float4* __restrict__ rqD,
+                                                      int* __restrict__ hitLeaf, uint32_t* __restrict__ seeds) {
+    const uint32_t slot = blockIdx.x * RTX_BLOCK + threadIdx.x;
+    if (slot >= (uint32_t)fr.numSlots) return;
+    int x, y;
+    if (slot_to_pixel(fr, tiles, slot, x, y)) {
+        uint32_t seed; F4 o, d;
+        primary_ray(fr, x, y, seed, o, d);
+        rqO[slot] = make_float4(o.x, o.y, o.z, __int_as_float((int)slot));
+        rqD[slot] = make_float4(d.x, d.y, d.z, 0.0f);
+        seeds[slot] = seed;
+    } else {
+        rqO[slot] = make_float4(0, 0, 0, __int_as_float((int)slot));
+        rqD[slot] = make_float4(0, 0, 0, 1.0f);
+        hitLeaf[slot] = RTX_INVALID_SLOT;
+    }
+}
+
 template <int MODE, bool COUNT>
 __global__ __launch_bounds__(RTX_BLOCK) void k_primary(DevScene sc, DevFrame fr, const int2* __restrict__ tiles,
                                                        float4* __restrict__ rqO, float4* __restrict__ rqD,
@@ -179,6 +202,152 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_trace(DevScene sc, const float4* 
     if (COUNT) {
         ic = wave_sum(ic); lc = wave_sum(lc);
         if ((threadIdx.x & 63) == 0) { atomicAdd(&stats[RTX_STAT_INNER(countIdx)], (unsigned long long)ic); atomicAdd(&stats[RTX_STAT_LEAF(countIdx)], (unsigned long long)lc); }
+    }
+}
+
+// Culled-mode trace launch with lane refill. Bounce rays are incoherent: in a wave of 64 the
+// traversal lengths differ by several x, and with one ray per lane per batch the wave runs as long
+// as its slowest ray. Here a lane that finishes its ray goes idle, and as soon as RTX_REFILL_MIN
+// lanes are idle (or the whole wave is) they pull the next rays of the queue — ballot + prefix
+// popcount over the idle mask, one device atomic per RTX_RESERVE rays — so the traversal loop keeps
+// running on well-filled waves. Per-ray results do not depend on which lane traced them.
+#ifndef RTX_REFILL_MIN
+#define RTX_REFILL_MIN 16
+#endif
+#ifndef RTX_RESERVE
+#define RTX_RESERVE 64u
+#endif
+#define RTX_IDLE ((int)0x80000002)
+
+template <bool COUNT>
+__global__ __launch_bounds__(RTX_BLOCK) void k_trace_refill(DevScene sc, const float4* __restrict__ rqO, const float4* __restrict__ rqD,
+                                                            float* __restrict__ hitT, int* __restrict__ hitLeaf,
+                                                            uint32_t* __restrict__ ctrl, unsigned long long* __restrict__ stats,
+                                                            uint32_t* __restrict__ slowList, uint32_t fixedCount,
+                                                            int countIdx, int workIdx) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const unsigned long long laneLt = (1ull << lane) - 1ull;
+    const long long nthreads = (long long)gridDim.x * RTX_BLOCK;
+    const long long gtid = (long long)blockIdx.x * RTX_BLOCK + threadIdx.x;
+    LaneStack st;
+    st.lds = (int)threadIdx.x; st.stride = RTX_BLOCK; st.spill = sc.spill + gtid; st.spillStride = nthreads; st.sp = 0; st.base = 0;
+    const float4* __restrict__ nodes = sc.fast ? sc.fast : sc.inner;
+    const int root = sc.fast ? sc.fastRoot : sc.rootRef;
+    const uint32_t count = countIdx == 0 ? fixedCount : ctrl[RTX_CTRL_COUNT(countIdx)];
+    uint32_t ic = 0, lc = 0;
+    uint32_t rcur = 0, rend = 0;          // wave-uniform: the wave's reserved run of the queue
+    bool drained = false;                 // wave-uniform
+    // per-lane ray state
+    int cur = RTX_IDLE;
+    uint32_t q = 0;
+    float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0, ix = 0, iy = 0, iz = 0;
+    Hit best; best.t = INFINITY; best.leaf = -1; best.box = -1;
+    float limit = INFINITY;
+    for (;;) {
+        const unsigned long long idle = __ballot(cur == RTX_IDLE);
+        const int nIdle = __popcll(idle);
+        if (nIdle == 64 && drained) break;
+        if (!drained && nIdle >= RTX_REFILL_MIN) {
+            if (rcur >= rend) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(&ctrl[RTX_CTRL_WORK(workIdx)], RTX_RESERVE);
+                rcur = __builtin_amdgcn_readfirstlane(base);
+                rend = rcur + RTX_RESERVE < count ? rcur + RTX_RESERVE : count;
+                if (rcur >= count) { drained = true; rend = rcur; }
+            }
+            if (!drained) {
+                const uint32_t avail = rend - rcur;
+                const uint32_t take = (uint32_t)nIdle < avail ? (uint32_t)nIdle : avail;
+                const uint32_t rank = (uint32_t)__popcll(idle & laneLt);
+                if (cur == RTX_IDLE && rank < take) {
+                    q = rcur + rank;
+                    const float4 o = rqO[q], d = rqD[q];
+                    ox = o.x; oy = o.y; oz = o.z; dx = d.x; dy = d.y; dz = d.z;
+                    if (d.w != 0.0f) {
+                        // slot outside the image: nothing to trace
+                    } else if (lane_is_clean(ox, oy, oz, dx, dy, dz)) {
+                        ix = 1.0f / dx; iy = 1.0f / dy; iz = 1.0f / dz;
+                        best.t = INFINITY; best.leaf = -1; best.box = -1; limit = INFINITY;
+                        st.sp = 0; st.base = 0;
+                        cur = root;
+                    } else {
+                        // axis-parallel / non-finite ray: k_trace_slow walks the reference topology for it
+                        slowList[atomicAdd(&ctrl[RTX_CTRL_SLOW(countIdx)], 1u)] = q;
+                    }
+                }
+                rcur += take;
+            }
+            continue;
+        }
+        if (cur != RTX_IDLE) {
+            if (cur == RTX_NEED_POP) {
+                if (st.sp == 0) {
+                    hitT[q] = best.t; hitLeaf[q] = best.leaf;
+                    cur = RTX_IDLE;
+                    continue;
+                }
+                st.sp--;
+                int ref; float tn;
+                if (st.sp >= st.base) {
+                    const int slot = st.sp & (RTX_LDS_WINDOW - 1);
+                    ref = rtx_lds[st.lds + slot * st.stride]; tn = __int_as_float(rtx_lds[st.lds + (RTX_LDS_WINDOW + slot) * st.stride]);
+                } else {
+                    const int2 e = st.spill[(long long)st.sp * st.spillStride];
+                    ref = e.x; tn = __int_as_float(e.y); st.base = st.sp;
+                }
+                if (tn > limit) continue;
+                cur = ref;
+            }
+            if (cur >= 0) {
+                const float4* N = nodes + (size_t)cur * 4;
+                float4 q0 = N[0], q1 = N[1], q2 = N[2], q3 = N[3];
+                if (COUNT) ic++;
+                float tn0, tn1;
+                bool p0 = slab_test_clean(ox, oy, oz, ix, iy, iz, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tn0);
+                bool p1 = slab_test_clean(ox, oy, oz, ix, iy, iz, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, tn1);
+                int c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
+                p0 = p0 && (c0 != RTX_NO_CHILD) && !(tn0 > limit);
+                p1 = p1 && (c1 != RTX_NO_CHILD) && !(tn1 > limit);
+                const bool swap = tn1 < tn0;
+                if (p0 && p1) st.push(swap ? c0 : c1, swap ? tn0 : tn1);
+                cur = (p0 && p1) ? (swap ? c1 : c0) : (p0 ? c0 : (p1 ? c1 : RTX_NEED_POP));
+            } else {
+                int leafIdx = ~cur, box;
+                float t = intersect_leaf(sc.leaf, leafIdx, ox, oy, oz, dx, dy, dz, box);
+                if (COUNT) lc++;
+                if (t > 0.01f && (t < best.t || (t == best.t && best.leaf >= 0 && box > best.box))) {
+                    best.t = t; best.leaf = leafIdx; best.box = box;
+                    limit = t + t * RTX_CULL_SLACK;
+                }
+                cur = RTX_NEED_POP;
+            }
+        }
+    }
+    if (COUNT) {
+        ic = wave_sum(ic); lc = wave_sum(lc);
+        if (lane == 0) { atomicAdd(&stats[RTX_STAT_INNER(countIdx)], (unsigned long long)ic); atomicAdd(&stats[RTX_STAT_LEAF(countIdx)], (unsigned long long)lc); }
+    }
+}
+
+// The few rays whose slab arithmetic can produce NaN (a zero direction component: 0*inf) keep the
+// reference's topology and the reference's exact semantics. Full-depth stack in LDS (small grid).
+template <bool COUNT>
+__global__ __launch_bounds__(RTX_BLOCK) void k_trace_slow(DevScene sc, const float4* __restrict__ rqO, const float4* __restrict__ rqD,
+                                                          float* __restrict__ hitT, int* __restrict__ hitLeaf,
+                                                          const uint32_t* __restrict__ ctrl, unsigned long long* __restrict__ stats,
+                                                          const uint32_t* __restrict__ slowList, int countIdx) {
+    int* stack = rtx_lds + threadIdx.x;
+    const uint32_t n = ctrl[RTX_CTRL_SLOW(countIdx)];
+    uint32_t ic = 0, lc = 0;
+    for (uint32_t i = blockIdx.x * RTX_BLOCK + threadIdx.x; i < n; i += gridDim.x * RTX_BLOCK) {
+        const uint32_t q = slowList[i];
+        const float4 o = rqO[q], d = rqD[q];
+        Hit h = traverse_bvh<true, COUNT>(sc, o.x, o.y, o.z, d.x, d.y, d.z, stack, RTX_BLOCK, ic, lc);
+        hitT[q] = h.t; hitLeaf[q] = h.leaf;
+    }
+    if (COUNT) {
+        ic = wave_sum(ic); lc = wave_sum(lc);
+        if ((threadIdx.x & 63) == 0 && (ic | lc)) { atomicAdd(&stats[RTX_STAT_INNER(countIdx)], (unsigned long long)ic); atomicAdd(&stats[RTX_STAT_LEAF(countIdx)], (unsigned long long)lc); }
     }
 }
 
