@@ -80,7 +80,7 @@ namespace {
 
 struct Flat {
     std::vector<float4> inner, leaf, shade;
-    std::vector<rtxbuild::Node> fast;   // own SAH tree over the same leaves (empty: not built)
+    std::vector<rtxbuild::Node4> fast;  // own 4-wide SAH tree over the same leaves (empty: not built)
     int rootRef = 0, fastRoot = 0;
     int maxDepth = 0, fastDepth = 0;
     bool nested = true;                 // every box contains its children (precondition of the own tree)
@@ -178,9 +178,25 @@ int flatten(const RtxSceneDesc& s, bool useBVH, bool wantFast, int nthreads, Fla
             prim[k].lo[0] = b.minimalPosition.x; prim[k].lo[1] = b.minimalPosition.y; prim[k].lo[2] = b.minimalPosition.z;
             prim[k].hi[0] = b.maximalPosition.x; prim[k].hi[1] = b.maximalPosition.y; prim[k].hi[2] = b.maximalPosition.z;
         }
-        f.fast.resize((size_t)nLeaf - 1);
-        f.fastRoot = rtxbuild::build_sah(prim.data(), (uint32_t)nLeaf, order.data(), f.fast.data(), nthreads, f.fastDepth);
-        if (f.fastDepth > 60) { f.fast.clear(); for (int32_t k = 0; k < nLeaf; ++k) order[k] = (uint32_t)k; }
+        std::vector<rtxbuild::Node> bin((size_t)nLeaf - 1);
+        int binDepth = 0;
+        const int32_t binRoot = rtxbuild::build_sah(prim.data(), (uint32_t)nLeaf, order.data(), bin.data(), nthreads, binDepth);
+        if (binDepth > 60) {
+            for (int32_t k = 0; k < nLeaf; ++k) order[k] = (uint32_t)k;      // degenerate input: keep the reference topology
+        } else {
+            f.fast.reserve((size_t)nLeaf / 2);
+            rtxbuild::collapse4(bin.data(), binRoot, f.fast, f.fastDepth);
+            f.fastRoot = 0;
+        }
+    } else if (wantFast && f.nested && nLeaf <= 1) {
+        rtxbuild::Box b;
+        if (nLeaf == 1) {
+            const RtxBoundingBox& lb = s.boxes[leafBox[0]];
+            b.lo[0] = lb.minimalPosition.x; b.lo[1] = lb.minimalPosition.y; b.lo[2] = lb.minimalPosition.z;
+            b.hi[0] = lb.maximalPosition.x; b.hi[1] = lb.maximalPosition.y; b.hi[2] = lb.maximalPosition.z;
+        }
+        rtxbuild::single_leaf_node4(nLeaf == 1 ? &b : nullptr, f.fast);
+        f.fastRoot = 0; f.fastDepth = 0;
     }
     // leaves in the new order; reference leaf index -> position
     std::vector<int32_t> posOf((size_t)nLeaf);
@@ -381,7 +397,7 @@ int rtx_create(const RtxSceneDesc* scene, const RtxConfig* cfgIn, RtxRenderer** 
     r->width = scene->width; r->height = scene->height;
     r->linear = !useBVH;
     // distance culling needs boxes that contain their descendants; otherwise keep the reference's visit set
-    r->mode = r->linear ? RTX_MODE_LINEAR : ((cfg.traversal == RTX_TRAVERSE_EXACT || !flat.nested) ? RTX_MODE_EXACT : RTX_MODE_CULLED);
+    r->mode = r->linear ? RTX_MODE_LINEAR : ((cfg.traversal == RTX_TRAVERSE_EXACT || !flat.nested || flat.fast.empty()) ? RTX_MODE_EXACT : RTX_MODE_CULLED);
     r->tileW = cfg.tileW; r->tileH = cfg.tileH;
 
 #define CREATE_TRY(expr) do { if (expr) { rtx_destroy(r); return 1; } } while (0)
@@ -418,7 +434,7 @@ int rtx_create(const RtxSceneDesc* scene, const RtxConfig* cfgIn, RtxRenderer** 
 
     // scene
     CREATE_TRY(upload(&r->dInner, flat.inner.data(), flat.inner.size() * sizeof(float4)));
-    if (!flat.fast.empty()) CREATE_TRY(upload(&r->dFast, flat.fast.data(), flat.fast.size() * sizeof(rtxbuild::Node)));
+    if (!flat.fast.empty()) CREATE_TRY(upload(&r->dFast, flat.fast.data(), flat.fast.size() * sizeof(rtxbuild::Node4)));
     CREATE_TRY(upload(&r->dLeaf, flat.leaf.data(), flat.leaf.size() * sizeof(float4)));
     CREATE_TRY(upload(&r->dShade, flat.shade.data(), flat.shade.size() * sizeof(float4)));
     CREATE_TRY(upload(&r->dMaterials, scene->materials, scene->numMaterials * sizeof(RtxMaterial)));
@@ -429,7 +445,7 @@ int rtx_create(const RtxSceneDesc* scene, const RtxConfig* cfgIn, RtxRenderer** 
     r->sc.texInfo = r->dTexInfo; r->sc.texels = r->dTexels;
     r->sc.numTexelsPadded = (long long)scene->numTexels + RTX_TEX_PAD;
     r->sc.rootRef = flat.rootRef;
-    r->sc.fast = r->dFast;            // NULL: the fast path walks the reference topology too
+    r->sc.fast = r->dFast;            // 4-wide nodes, 8 float4 each (NULL unless mode == RTX_MODE_CULLED)
     r->sc.fastRoot = flat.fastRoot;
     r->sc.numLeaves = (int)(flat.leaf.size() / 4);
     r->sc.numInner = (int)(flat.inner.size() / 4);
@@ -439,7 +455,8 @@ int rtx_create(const RtxSceneDesc* scene, const RtxConfig* cfgIn, RtxRenderer** 
     // single texture the reference reads past the vector, here texture 0 is used
     r->sc.skyTex = scene->numTextures > 1 ? 1 : 0;
     r->sc.useBVH = useBVH ? 1 : 0;
-    r->sc.stackDepth = std::max(2, std::max(flat.maxDepth, flat.fast.empty() ? 0 : flat.fastDepth) + 2);
+    // reference topology: one pending entry per level; 4-wide tree: up to three per level
+    r->sc.stackDepth = std::max(2, std::max(flat.maxDepth, flat.fast.empty() ? 0 : 3 * (flat.fastDepth + 1)) + 2);
 
     // per-path state and queues
     const size_t n = std::max<size_t>(r->numSlots, 64);

@@ -132,4 +132,82 @@ inline int32_t build_sah(const Box* prim, uint32_t n, uint32_t* order, Node* nod
     return ref;
 }
 
+// ---- 4-wide collapse --------------------------------------------------------------
+// A traversal step costs the wave one dependent memory round trip plus the fixed overhead of the
+// pop / push / leaf sections, so the binary tree is folded into nodes of up to four children: a
+// node's children are replaced by their own children, largest box first, until four are held.
+// Child boxes are copied unchanged (a leaf child keeps its exact leaf box), so the traversal
+// semantics do not change; only the number of steps does.
+struct Node4 {          // 128-byte record: lo.x[4] lo.y[4] lo.z[4] hi.x[4] hi.y[4] hi.z[4] ref[4] pad[4]
+    float q[32];
+};
+
+struct Collapser {
+    const Node* bvh2;
+    std::vector<Node4>& out;
+    int maxDepth = 0;
+
+    struct Child { Box box; int32_t ref; };
+
+    static void children_of(const Node& n, Child c[2]) {
+        for (int k = 0; k < 2; ++k) {
+            for (int a = 0; a < 3; ++a) { c[k].box.lo[a] = n.q[6 * k + a]; c[k].box.hi[a] = n.q[6 * k + 3 + a]; }
+            c[k].ref = f2i(n.q[12 + k]);
+        }
+    }
+
+    // emits the wide node for binary node `ref2` (>= 0) and returns its index
+    int32_t emit(int32_t ref2, int depth) {
+        maxDepth = std::max(maxDepth, depth);
+        Child c[4]; int n = 2;
+        children_of(bvh2[ref2], c);
+        while (n < 4) {
+            int pick = -1; double bestArea = -1.0;
+            for (int k = 0; k < n; ++k) if (c[k].ref >= 0) { double a = half_area(c[k].box); if (a > bestArea) { bestArea = a; pick = k; } }
+            if (pick < 0) break;
+            Child g[2];
+            children_of(bvh2[c[pick].ref], g);
+            c[pick] = g[0];
+            c[n++] = g[1];
+        }
+        const int32_t idx = (int32_t)out.size();
+        out.emplace_back();
+        int32_t refs[4];
+        for (int k = 0; k < 4; ++k) {
+            if (k < n) refs[k] = c[k].ref >= 0 ? emit(c[k].ref, depth + 1) : c[k].ref;
+            else refs[k] = (int32_t)0x80000000;                       // RTX_NO_CHILD
+        }
+        float* q = out[idx].q;
+        for (int k = 0; k < 4; ++k) {
+            const bool used = k < n;
+            for (int a = 0; a < 3; ++a) {
+                q[4 * a + k] = used ? c[k].box.lo[a] : NAN;           // an empty slot never passes the slab test:
+                q[12 + 4 * a + k] = used ? c[k].box.hi[a] : NAN;      // every comparison with its NaN distances is false
+            }
+            q[24 + k] = i2f(refs[k]);
+            q[28 + k] = 0.0f;
+        }
+        return idx;
+    }
+};
+
+// Folds the binary tree rooted at inner node `root2` into 4-wide nodes (root = index 0).
+inline void collapse4(const Node* bvh2, int32_t root2, std::vector<Node4>& out, int& maxDepth) {
+    Collapser c{bvh2, out};
+    c.emit(root2, 0);
+    maxDepth = c.maxDepth;
+}
+
+// A wide node holding a single leaf (scenes with one primitive) or nothing at all.
+inline void single_leaf_node4(const Box* leafBox, std::vector<Node4>& out) {
+    out.emplace_back();
+    float* q = out.back().q;
+    for (int k = 0; k < 4; ++k) {
+        const bool used = leafBox && k == 0;
+        for (int a = 0; a < 3; ++a) { q[4 * a + k] = used ? leafBox->lo[a] : NAN; q[12 + 4 * a + k] = used ? leafBox->hi[a] : NAN; }
+        q[24 + k] = i2f(used ? ~0 : (int32_t)0x80000000);
+        q[28 + k] = 0.0f;
+    }
+}
+
 } // namespace rtxbuild

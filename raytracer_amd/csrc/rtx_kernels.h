@@ -231,8 +231,8 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_trace_refill(DevScene sc, const f
     const long long gtid = (long long)blockIdx.x * RTX_BLOCK + threadIdx.x;
     LaneStack st;
     st.lds = (int)threadIdx.x; st.stride = RTX_BLOCK; st.spill = sc.spill + gtid; st.spillStride = nthreads; st.sp = 0; st.base = 0;
-    const float4* __restrict__ nodes = sc.fast ? sc.fast : sc.inner;
-    const int root = sc.fast ? sc.fastRoot : sc.rootRef;
+    const float4* __restrict__ nodes = sc.fast;
+    const int root = sc.fastRoot;
     const uint32_t count = countIdx == 0 ? fixedCount : ctrl[RTX_CTRL_COUNT(countIdx)];
     uint32_t ic = 0, lc = 0;
     uint32_t rcur = 0, rend = 0;          // wave-uniform: the wave's reserved run of the queue
@@ -299,18 +299,8 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_trace_refill(DevScene sc, const f
                 cur = ref;
             }
             if (cur >= 0) {
-                const float4* N = nodes + (size_t)cur * 4;
-                float4 q0 = N[0], q1 = N[1], q2 = N[2], q3 = N[3];
                 if (COUNT) ic++;
-                float tn0, tn1;
-                bool p0 = slab_test_clean(ox, oy, oz, ix, iy, iz, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tn0);
-                bool p1 = slab_test_clean(ox, oy, oz, ix, iy, iz, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, tn1);
-                int c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
-                p0 = p0 && (c0 != RTX_NO_CHILD) && !(tn0 > limit);
-                p1 = p1 && (c1 != RTX_NO_CHILD) && !(tn1 > limit);
-                const bool swap = tn1 < tn0;
-                if (p0 && p1) st.push(swap ? c0 : c1, swap ? tn0 : tn1);
-                cur = (p0 && p1) ? (swap ? c1 : c0) : (p0 ? c0 : (p1 ? c1 : RTX_NEED_POP));
+                cur = wide_step(nodes, cur, ox, oy, oz, ix, iy, iz, limit, st);
             } else {
                 int leafIdx = ~cur, box;
                 float t = intersect_leaf(sc.leaf, leafIdx, ox, oy, oz, dx, dy, dz, box);

@@ -89,14 +89,14 @@ __device__ __forceinline__ float intersect_leaf(const float4* __restrict__ leafB
 // BVH closest hit. `stack` is this lane's LDS stack: entry k at stack[k * stride].
 template <bool EXACT, bool COUNT>
 __device__ __forceinline__ Hit traverse_bvh(const DevScene& sc, float ox, float oy, float oz, float dx, float dy, float dz,
-                                            int* stack, int stride, uint32_t& innerCount, uint32_t& leafCount, bool useOwn = false) {
+                                            int* stack, int stride, uint32_t& innerCount, uint32_t& leafCount) {
     Hit best; best.t = INFINITY; best.leaf = -1; best.box = -1;
     const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;
     // Reference topology, reference arithmetic (SSE min/max NaN rule). EXACT = no distance culling.
     const bool cull = !EXACT;
-    const float4* __restrict__ nodes = useOwn ? sc.fast : sc.inner;
+    const float4* __restrict__ nodes = sc.inner;
     int sp = 0;
-    int cur = useOwn ? sc.fastRoot : sc.rootRef;
+    int cur = sc.rootRef;
     const int maxSp = sc.stackDepth;
     for (;;) {
         if (cur >= 0) {
@@ -191,18 +191,48 @@ struct LaneStack {
 
 #define RTX_NEED_POP ((int)0x80000001)
 
-// Fast path for clean lanes (RTX_TRAVERSE_CULLED): own SAH tree when present (else the reference
-// topology), near-first order, distance culling at push and at pop. One flat loop: every pass does
-// at most one pop, then one inner step or one leaf test per lane — no nested per-lane loops for the
-// wave to serialise (nested while-while forms measured 1.8x slower here).
+#define RTX_CSWAP(ta, ra, tb, rb) { const bool s_ = tb < ta; const float tt_ = s_ ? ta : tb; const int rr_ = s_ ? ra : rb; \
+                                    ta = s_ ? tb : ta; ra = s_ ? rb : ra; tb = tt_; rb = rr_; }
+
+// One step through a 4-wide node (rtx_build.h Node4: lo.x[4] lo.y[4] lo.z[4] hi.x[4] hi.y[4] hi.z[4] ref[4]):
+// tests the four child boxes, drops those that miss or start beyond `limit`, orders the rest by
+// entry distance, pushes all but the nearest (farthest first) and returns the nearest — or
+// RTX_NEED_POP when none is left. Empty slots hold NaN boxes: their distances compare false and never pass.
+__device__ __forceinline__ int wide_step(const float4* __restrict__ nodes, int cur, float ox, float oy, float oz,
+                                         float ix, float iy, float iz, float limit, LaneStack& st) {
+    const float4* N = nodes + (size_t)cur * 8;
+    const float4 lx = N[0], ly = N[1], lz = N[2], hx = N[3], hy = N[4], hz = N[5], rf = N[6];
+    float t0, t1, t2, t3;
+    const bool p0 = slab_test_clean(ox, oy, oz, ix, iy, iz, lx.x, ly.x, lz.x, hx.x, hy.x, hz.x, t0) && !(t0 > limit);
+    const bool p1 = slab_test_clean(ox, oy, oz, ix, iy, iz, lx.y, ly.y, lz.y, hx.y, hy.y, hz.y, t1) && !(t1 > limit);
+    const bool p2 = slab_test_clean(ox, oy, oz, ix, iy, iz, lx.z, ly.z, lz.z, hx.z, hy.z, hz.z, t2) && !(t2 > limit);
+    const bool p3 = slab_test_clean(ox, oy, oz, ix, iy, iz, lx.w, ly.w, lz.w, hx.w, hy.w, hz.w, t3) && !(t3 > limit);
+    int r0 = __float_as_int(rf.x), r1 = __float_as_int(rf.y), r2 = __float_as_int(rf.z), r3 = __float_as_int(rf.w);
+    t0 = p0 ? t0 : INFINITY; t1 = p1 ? t1 : INFINITY; t2 = p2 ? t2 : INFINITY; t3 = p3 ? t3 : INFINITY;
+    r0 = p0 ? r0 : RTX_NEED_POP; r1 = p1 ? r1 : RTX_NEED_POP; r2 = p2 ? r2 : RTX_NEED_POP; r3 = p3 ? r3 : RTX_NEED_POP;
+    const int n = (int)p0 + (int)p1 + (int)p2 + (int)p3;
+    // a passing entry distance is finite or -inf, so misses (+inf) sort last
+    RTX_CSWAP(t0, r0, t1, r1) RTX_CSWAP(t2, r2, t3, r3) RTX_CSWAP(t0, r0, t2, r2) RTX_CSWAP(t1, r1, t3, r3) RTX_CSWAP(t1, r1, t2, r2)
+    if (n > 1) {
+        if (n > 3) st.push(r3, t3);
+        if (n > 2) st.push(r2, t2);
+        st.push(r1, t1);
+    }
+    return r0;
+}
+
+// Fast path for clean lanes (RTX_TRAVERSE_CULLED): own 4-wide SAH tree over the reference's leaves,
+// near-first order, distance culling at push and at pop. One flat loop: every pass does at most one
+// pop, then one node step or one leaf test per lane — no nested per-lane loops for the wave to
+// serialise (nested while-while forms measured 1.8x slower here).
 template <bool COUNT>
 __device__ __forceinline__ Hit traverse_fast(const DevScene& sc, float ox, float oy, float oz, float dx, float dy, float dz,
                                              LaneStack st, uint32_t& innerCount, uint32_t& leafCount) {
     Hit best; best.t = INFINITY; best.leaf = -1; best.box = -1;
     const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;
-    const float4* __restrict__ nodes = sc.fast ? sc.fast : sc.inner;
+    const float4* __restrict__ nodes = sc.fast;
     st.sp = 0; st.base = 0;
-    int cur = sc.fast ? sc.fastRoot : sc.rootRef;
+    int cur = sc.fastRoot;
     float limit = INFINITY;
     for (;;) {
         if (cur == RTX_NEED_POP) {
@@ -220,18 +250,8 @@ __device__ __forceinline__ Hit traverse_fast(const DevScene& sc, float ox, float
             cur = ref;
         }
         if (cur >= 0) {
-            const float4* N = nodes + (size_t)cur * 4;
-            float4 q0 = N[0], q1 = N[1], q2 = N[2], q3 = N[3];
             if (COUNT) innerCount++;
-            float tn0, tn1;
-            bool p0 = slab_test_clean(ox, oy, oz, ix, iy, iz, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tn0);
-            bool p1 = slab_test_clean(ox, oy, oz, ix, iy, iz, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, tn1);
-            int c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
-            p0 = p0 && (c0 != RTX_NO_CHILD) && !(tn0 > limit);
-            p1 = p1 && (c1 != RTX_NO_CHILD) && !(tn1 > limit);
-            const bool swap = tn1 < tn0;
-            if (p0 && p1) st.push(swap ? c0 : c1, swap ? tn0 : tn1);
-            cur = (p0 && p1) ? (swap ? c1 : c0) : (p0 ? c0 : (p1 ? c1 : RTX_NEED_POP));
+            cur = wide_step(nodes, cur, ox, oy, oz, ix, iy, iz, limit, st);
         } else {
             int leafIdx = ~cur, box;
             float t = intersect_leaf(sc.leaf, leafIdx, ox, oy, oz, dx, dy, dz, box);
