@@ -458,14 +458,21 @@ int rtx_create(const RtxSceneDesc* scene, const RtxConfig* cfgIn, RtxRenderer** 
     // reference topology: one pending entry per level; 4-wide tree: up to three per level
     r->sc.stackDepth = std::max(2, std::max(flat.maxDepth, flat.fast.empty() ? 0 : 3 * (flat.fastDepth + 1)) + 2);
 
-    // per-path state and queues
+    // persistent shade grid: as many blocks as are resident at once
+    int shadeBlocksPerCU = 0;
+    CREATE_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&shadeBlocksPerCU, k_shade, RTX_BLOCK, 0));
+    r->gridShade = r->numCUs * std::max(1, std::min(shadeBlocksPerCU, 8));
+
+    // per-path state (indexed by slot) and queues (indexed by queue position; the bounce queues hold
+    // up to one unfinished run of holes per shade wave on top of the live rays)
     const size_t n = std::max<size_t>(r->numSlots, 64);
+    const size_t nq = n + (size_t)r->gridShade * (RTX_BLOCK / 64) * RTX_MAX_RUN;
     for (int k = 0; k < 2; ++k) {
-        CREATE_HIP(hipMalloc((void**)&r->dRqO[k], n * sizeof(float4)));
-        CREATE_HIP(hipMalloc((void**)&r->dRqD[k], n * sizeof(float4)));
+        CREATE_HIP(hipMalloc((void**)&r->dRqO[k], nq * sizeof(float4)));
+        CREATE_HIP(hipMalloc((void**)&r->dRqD[k], nq * sizeof(float4)));
     }
-    CREATE_HIP(hipMalloc((void**)&r->dHitT, n * sizeof(float)));
-    CREATE_HIP(hipMalloc((void**)&r->dHitLeaf, n * sizeof(int)));
+    CREATE_HIP(hipMalloc((void**)&r->dHitT, nq * sizeof(float)));
+    CREATE_HIP(hipMalloc((void**)&r->dHitLeaf, nq * sizeof(int)));
     CREATE_HIP(hipMalloc((void**)&r->dLight, n * sizeof(float4)));
     CREATE_HIP(hipMalloc((void**)&r->dAcc, n * sizeof(float4)));
     CREATE_HIP(hipMalloc((void**)&r->dSeeds, n * sizeof(uint32_t)));
@@ -483,10 +490,9 @@ int rtx_create(const RtxSceneDesc* scene, const RtxConfig* cfgIn, RtxRenderer** 
     int blocksPerCU = 8;
     if (r->ldsTrace) blocksPerCU = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / r->ldsTrace));
     r->gridTrace = r->numCUs * blocksPerCU;
-    r->gridShade = r->numCUs * 4;
     if (r->mode == RTX_MODE_CULLED) {
         r->ldsSlow = (size_t)std::max(2, flat.maxDepth + 2) * RTX_BLOCK * sizeof(int);
-        CREATE_HIP(hipMalloc((void**)&r->dSlow, n * sizeof(uint32_t)));
+        CREATE_HIP(hipMalloc((void**)&r->dSlow, nq * sizeof(uint32_t)));
         CREATE_HIP(hipMalloc((void**)&r->dSpill, (size_t)r->sc.stackDepth * r->gridTrace * RTX_BLOCK * sizeof(int2)));
         r->sc.spill = r->dSpill;
     }
@@ -494,7 +500,8 @@ int rtx_create(const RtxSceneDesc* scene, const RtxConfig* cfgIn, RtxRenderer** 
     if (getenv("RTX_VERBOSE"))
         fprintf(stderr, "[rtx] %d leaves, reference tree depth %d, own tree %s depth %d, stack %d entries, LDS %zu B/block, %d blocks/CU x %d CUs, mode %d\n",
                 r->sc.numLeaves, flat.maxDepth, flat.fast.empty() ? "absent" : "built", flat.fastDepth, r->sc.stackDepth, r->ldsTrace,
-                blocksPerCU, r->numCUs, r->mode);
+                blocksPerCU, r->numCUs, r->mode),
+        fprintf(stderr, "[rtx] shade grid %d blocks (%d per CU), queue capacity %zu entries for %zu slots\n", r->gridShade, shadeBlocksPerCU, nq, n);
     *out = r;
     return 0;
 }
@@ -523,7 +530,7 @@ static int render_frame(RtxRenderer* r, const RtxCamera* cam, uint32_t fc, bool 
             HIP_TRY(hipEventRecord(ev[2 * b + 2], r->stream));
             in ^= 1;
         }
-        hipLaunchKernelGGL(k_fold_counts, dim3(1), dim3(64), 0, r->stream, r->dCtrl, r->dStats, (uint32_t)r->localPixels);
+        hipLaunchKernelGGL(k_fold_counts, dim3(1), dim3(64), 0, r->stream, r->dStats, (uint32_t)r->localPixels);
         HIP_TRY(hipEventRecord(ev[kEvents - 1], r->stream));
         r->pending[slot] = true;
         r->totals.frames++;

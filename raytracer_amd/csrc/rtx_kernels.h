@@ -71,6 +71,16 @@ struct WorkIter {
     }
 };
 
+// Length of the wave-private runs k_shade reserves in the next queue: long enough that the shared
+// counter sees few atomics, short enough that the holes left at the end (half a run per wave on
+// average) stay a few percent of the queue. RTX_MAX_RUN bounds the queue slack rtx_create allocates.
+#define RTX_MAX_RUN 512u
+__device__ __forceinline__ uint32_t append_run_length(uint32_t count) {
+    const uint32_t waves = gridDim.x * (RTX_BLOCK / 64u);
+    const uint32_t g = (count / (8u * waves)) & ~63u;
+    return g < 64u ? 64u : (g > RTX_MAX_RUN ? RTX_MAX_RUN : g);
+}
+
 __device__ __forceinline__ bool slot_to_pixel(const DevFrame& fr, const int2* __restrict__ tiles, uint32_t slot, int& x, int& y) {
     const uint32_t perTile = (uint32_t)(fr.tileW * fr.tileH);
     const uint32_t tile = slot / perTile, within = slot % perTile;
@@ -145,6 +155,9 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_raygen(DevFrame fr, const int2* _
     }
 }
 
+#ifndef RTX_PRIMARY_GUIDE
+#define RTX_PRIMARY_GUIDE 0
+#endif
 template <int MODE, bool COUNT>
 __global__ __launch_bounds__(RTX_BLOCK) void k_primary(DevScene sc, DevFrame fr, const int2* __restrict__ tiles,
                                                        float4* __restrict__ rqO, float4* __restrict__ rqD,
@@ -154,7 +167,7 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_primary(DevScene sc, DevFrame fr,
     int* stack = rtx_lds + threadIdx.x;
     uint32_t ic = 0, lc = 0;
     const int countIdx = 0;
-    WorkIter<0> work((uint32_t)fr.numSlots);
+    WorkIter<RTX_PRIMARY_GUIDE> work((uint32_t)fr.numSlots);
     for (;;) {
         const uint32_t base = work.next(&ctrl[RTX_CTRL_WORK(workIdx)], (uint32_t)fr.numSlots);
         if (base == 0xffffffffu) break;
@@ -194,9 +207,13 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_trace(DevScene sc, const float4* 
         const uint32_t q = base + (threadIdx.x & 63u);
         if (q < count) {
             float4 o = rqO[q], d = rqD[q];
-            Hit h = closest_hit<MODE, COUNT>(sc, o.x, o.y, o.z, d.x, d.y, d.z, stack, ic, lc);
-            hitT[q] = h.t;
-            hitLeaf[q] = h.leaf;
+            if (d.w != 0.0f) {
+                hitLeaf[q] = RTX_INVALID_SLOT;      // hole left by k_shade's run reservation
+            } else {
+                Hit h = closest_hit<MODE, COUNT>(sc, o.x, o.y, o.z, d.x, d.y, d.z, stack, ic, lc);
+                hitT[q] = h.t;
+                hitLeaf[q] = h.leaf;
+            }
         }
     }
     if (COUNT) {
@@ -264,7 +281,7 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_trace_refill(DevScene sc, const f
                     const float4 o = rqO[q], d = rqD[q];
                     ox = o.x; oy = o.y; oz = o.z; dx = d.x; dy = d.y; dz = d.z;
                     if (d.w != 0.0f) {
-                        // slot outside the image: nothing to trace
+                        hitLeaf[q] = RTX_INVALID_SLOT;     // slot outside the image, or a hole in a bounce queue
                     } else if (lane_is_clean(ox, oy, oz, dx, dy, dz)) {
                         ix = 1.0f / dx; iy = 1.0f / dy; iz = 1.0f / dz;
                         best.t = INFINITY; best.leaf = -1; best.box = -1; limit = INFINITY;
@@ -353,6 +370,12 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_shade(DevScene sc, DevFrame fr, c
     const uint32_t count = bounce == 0 ? (uint32_t)fr.numSlots : ctrl[RTX_CTRL_COUNT(bounce)];
     const F4 camPos = mk4(fr.pos[0], fr.pos[1], fr.pos[2]);
     uint32_t hits = 0;
+    // Survivors go to the next queue in wave-private runs: one device atomic reserves `run` entries,
+    // the wave fills them densely across iterations, and what is left of its last run when the kernel
+    // ends is marked as holes (rqD.w = 1), which the trace kernels skip. One atomic per 64 paths on a
+    // single counter was the bottleneck of this kernel (same-address atomics retire at ~8 ns each).
+    const uint32_t run = append_run_length(count);
+    uint32_t outCur = 0, outEnd = 0;      // wave-uniform
     WorkIter<2> work(count);
     for (;;) {
         const uint32_t base = work.next(&ctrl[RTX_CTRL_WORK(workIdx)], count);
@@ -401,28 +424,37 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_shade(DevScene sc, DevFrame fr, c
         // regroup survivors: dense positions in the next queue
         const unsigned long long m = __ballot(alive);
         if (m) {
-            uint32_t qbase = 0;
-            if (lane == 0) qbase = atomicAdd(&ctrl[RTX_CTRL_COUNT(bounce + 1)], (uint32_t)__popcll(m));
-            qbase = __builtin_amdgcn_readfirstlane(qbase);
+            const uint32_t n = (uint32_t)__popcll(m), room = outEnd - outCur;
+            uint32_t fresh = 0;
+            if (n > room) {
+                if (lane == 0) fresh = atomicAdd(&ctrl[RTX_CTRL_COUNT(bounce + 1)], run);
+                fresh = __builtin_amdgcn_readfirstlane(fresh);
+            }
             if (alive) {
-                const uint32_t pos = qbase + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                const uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                const uint32_t pos = rank < room ? outCur + rank : fresh + (rank - room);
                 rqOout[pos] = make_float4(o.x, o.y, o.z, __int_as_float(slot));
                 rqDout[pos] = make_float4(d.x, d.y, d.z, 0.0f);
                 lightArr[slot] = make_float4(light.x, light.y, light.z, light.w);
                 accArr[slot] = make_float4(acc.x, acc.y, acc.z, acc.w);
                 seeds[slot] = seed;
             }
+            if (n > room) { outCur = fresh + (n - room); outEnd = fresh + run; }
+            else outCur += n;
         }
     }
+    for (uint32_t i = outCur + lane; i < outEnd; i += 64u) rqDout[i] = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
     hits = wave_sum(hits);
     if (lane == 0 && hits) atomicAdd(&stats[RTX_STAT_HITS(bounce)], (unsigned long long)hits);
 }
 
-// after the last shade: fold this frame's queue lengths into the 64-bit totals
-__global__ void k_fold_counts(const uint32_t* __restrict__ ctrl, unsigned long long* __restrict__ stats, uint32_t primaryRays) {
+// after the last shade: fold this frame's ray counts into the 64-bit totals. The queue lengths in
+// ctrl include the holes of k_shade's run reservation, so the rays of bounce b+1 are counted as what
+// they are: the hits of bounce b (every hit before the last bounce continues, src/ThreadedShader.cpp:155-177).
+__global__ void k_fold_counts(unsigned long long* __restrict__ stats, uint32_t primaryRays) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         stats[RTX_STAT_RAYS(0)] += primaryRays;
-        for (int b = 1; b < 4; ++b) stats[RTX_STAT_RAYS(b)] += ctrl[RTX_CTRL_COUNT(b)];
+        for (int b = 1; b < 4; ++b) stats[RTX_STAT_RAYS(b)] = stats[RTX_STAT_HITS(b - 1)];
     }
 }
 
