@@ -151,6 +151,8 @@ typedef struct RtxCounters {
     /* per launch of the frame pipeline, summed over `frames` (HIP events on the
      * renderer's stream): [0] primary, [1] shade0, [2] trace1, [3] shade1, ... [7] shade3 */
     double   kernelMs[8];
+    uint64_t wavePasses[4];   /* traversal-loop passes of whole 64-lane waves, per bounce (countStats, culled bounce
+                                 launches only): (innerVisits + leafTests) / (64 * wavePasses) = lane utilisation */
 } RtxCounters;
 
 typedef struct RtxRenderer RtxRenderer;

@@ -43,7 +43,7 @@ class Counters(C.Structure):
                 ("raysPerBounce", C.c_uint64 * 4), ("hitsPerBounce", C.c_uint64 * 4),
                 ("innerVisits", C.c_uint64 * 4), ("leafTests", C.c_uint64 * 4),
                 ("lastFrameMs", C.c_double), ("lastTraceMs", C.c_double), ("lastShadeMs", C.c_double),
-                ("totalMs", C.c_double), ("kernelMs", C.c_double * 8)]
+                ("totalMs", C.c_double), ("kernelMs", C.c_double * 8), ("wavePasses", C.c_uint64 * 4)]
 
 
 # numpy mirrors of the reference PODs (sizes/offsets as in include/rtx.h)

@@ -152,6 +152,10 @@ int flatten(const RtxSceneDesc& s, bool useBVH, bool wantFast, int nthreads, Fla
             seen[b] = 1;
             maxDepth = std::max(maxDepth, depth);
             const RtxBoundingBox& box = s.boxes[b];
+            // the fast path picks a box's near and far planes by the sign of the ray direction, which
+            // equals the reference's min/max of the two plane distances only when min <= max (NaN fails too)
+            if (b != 0 && !(box.minimalPosition.x <= box.maximalPosition.x && box.minimalPosition.y <= box.maximalPosition.y &&
+                            box.minimalPosition.z <= box.maximalPosition.z)) f.nested = false;
             if (box.objectID != -1) continue;
             const int32_t child[2] = {box.leftID, box.rightID};
             for (int k = 0; k < 2; ++k) {
@@ -187,6 +191,10 @@ int flatten(const RtxSceneDesc& s, bool useBVH, bool wantFast, int nthreads, Fla
             f.fast.reserve((size_t)nLeaf / 2);
             rtxbuild::collapse4(bin.data(), binRoot, f.fast, f.fastDepth);
             f.fastRoot = 0;
+            if (f.fast.size() > ((size_t)1 << 25)) {      // the kernels address nodes with 32-bit byte offsets (4 GiB)
+                f.fast.clear(); f.fast.shrink_to_fit();
+                for (int32_t k = 0; k < nLeaf; ++k) order[k] = (uint32_t)k;
+            }
         }
     } else if (wantFast && f.nested && nLeaf <= 1) {
         rtxbuild::Box b;
@@ -287,13 +295,13 @@ void launch_primary(RtxRenderer* r, const DevFrame& fr, int workIdx) {
                            r->dRqO[0], r->dRqD[0], r->dHitT, r->dHitLeaf, r->dSeeds, r->dCtrl, r->dStats, workIdx);
 }
 template <int MODE>
-void launch_trace(RtxRenderer* r, const float4* o, const float4* d, int countIdx, int workIdx) {
+void launch_trace(RtxRenderer* r, const float4* o, const float4* d, int countIdx, int workIdx, uint32_t fixedCount) {
     if (r->cfg.countStats)
         hipLaunchKernelGGL((k_trace<MODE, true>), dim3(r->gridTrace), dim3(RTX_BLOCK), r->ldsTrace, r->stream, r->sc, o, d,
-                           r->dHitT, r->dHitLeaf, r->dCtrl, r->dStats, countIdx, workIdx);
+                           r->dHitT, r->dHitLeaf, r->dCtrl, r->dStats, fixedCount, countIdx, workIdx);
     else
         hipLaunchKernelGGL((k_trace<MODE, false>), dim3(r->gridTrace), dim3(RTX_BLOCK), r->ldsTrace, r->stream, r->sc, o, d,
-                           r->dHitT, r->dHitLeaf, r->dCtrl, r->dStats, countIdx, workIdx);
+                           r->dHitT, r->dHitLeaf, r->dCtrl, r->dStats, fixedCount, countIdx, workIdx);
 }
 void dispatch_primary(RtxRenderer* r, const DevFrame& fr, int workIdx) {
     // Bounce 0 is coherent (one 8x8 pixel block per wave): the fused generate+trace kernel measured
@@ -302,7 +310,8 @@ void dispatch_primary(RtxRenderer* r, const DevFrame& fr, int workIdx) {
         if (r->numSlots == 0) return;
         hipLaunchKernelGGL(k_raygen, dim3((r->numSlots + RTX_BLOCK - 1) / RTX_BLOCK), dim3(RTX_BLOCK), 0, r->stream, fr, r->dTiles,
                            r->dRqO[0], r->dRqD[0], r->dHitLeaf, r->dSeeds);
-        dispatch_trace(r, r->dRqO[0], r->dRqD[0], 0, workIdx, r->numSlots);
+        if (atoi(getenv("RTX_SPLIT_PRIMARY")) == 2) launch_trace<RTX_MODE_CULLED>(r, r->dRqO[0], r->dRqD[0], 0, workIdx, r->numSlots);
+        else dispatch_trace(r, r->dRqO[0], r->dRqD[0], 0, workIdx, r->numSlots);
         return;
     }
     if (r->mode == RTX_MODE_LINEAR) launch_primary<RTX_MODE_LINEAR>(r, fr, workIdx);
@@ -325,9 +334,9 @@ void dispatch_trace(RtxRenderer* r, const float4* o, const float4* d, int countI
         }
         return;
     }
-    if (r->mode == RTX_MODE_LINEAR) launch_trace<RTX_MODE_LINEAR>(r, o, d, countIdx, workIdx);
-    else if (r->mode == RTX_MODE_EXACT) launch_trace<RTX_MODE_EXACT>(r, o, d, countIdx, workIdx);
-    else launch_trace<RTX_MODE_CULLED>(r, o, d, countIdx, workIdx);
+    if (r->mode == RTX_MODE_LINEAR) launch_trace<RTX_MODE_LINEAR>(r, o, d, countIdx, workIdx, fixedCount);
+    else if (r->mode == RTX_MODE_EXACT) launch_trace<RTX_MODE_EXACT>(r, o, d, countIdx, workIdx, fixedCount);
+    else launch_trace<RTX_MODE_CULLED>(r, o, d, countIdx, workIdx, fixedCount);
 }
 
 int check_camera(const RtxCamera* cam) {
@@ -663,7 +672,7 @@ int rtx_get_counters(RtxRenderer* r, RtxCounters* out) {
     RtxCounters c = r->totals;
     c.rays = 0;
     for (int b = 0; b < 4; ++b) { c.raysPerBounce[b] = st[RTX_STAT_RAYS(b)]; c.hitsPerBounce[b] = st[RTX_STAT_HITS(b)]; c.rays += st[RTX_STAT_RAYS(b)]; }
-    for (int b = 0; b < 4; ++b) { c.innerVisits[b] = st[RTX_STAT_INNER(b)]; c.leafTests[b] = st[RTX_STAT_LEAF(b)]; }
+    for (int b = 0; b < 4; ++b) { c.innerVisits[b] = st[RTX_STAT_INNER(b)]; c.leafTests[b] = st[RTX_STAT_LEAF(b)]; c.wavePasses[b] = st[RTX_STAT_PASSES(b)]; }
     *out = c;
     return 0;
 }

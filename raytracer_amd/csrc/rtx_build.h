@@ -138,7 +138,7 @@ inline int32_t build_sah(const Box* prim, uint32_t n, uint32_t* order, Node* nod
 // node's children are replaced by their own children, largest box first, until four are held.
 // Child boxes are copied unchanged (a leaf child keeps its exact leaf box), so the traversal
 // semantics do not change; only the number of steps does.
-struct Node4 {          // 128-byte record: lo.x[4] lo.y[4] lo.z[4] hi.x[4] hi.y[4] hi.z[4] ref[4] pad[4]
+struct Node4 {          // 128-byte record: lo.x[4] hi.x[4] lo.y[4] hi.y[4] lo.z[4] hi.z[4] ref[4] pad[4]
     float q[32];
 };
 
@@ -181,8 +181,8 @@ struct Collapser {
         for (int k = 0; k < 4; ++k) {
             const bool used = k < n;
             for (int a = 0; a < 3; ++a) {
-                q[4 * a + k] = used ? c[k].box.lo[a] : NAN;           // an empty slot never passes the slab test:
-                q[12 + 4 * a + k] = used ? c[k].box.hi[a] : NAN;      // every comparison with its NaN distances is false
+                q[8 * a + k] = used ? c[k].box.lo[a] : NAN;           // an empty slot never passes the slab test:
+                q[8 * a + 4 + k] = used ? c[k].box.hi[a] : NAN;       // every comparison with its NaN distances is false
             }
             q[24 + k] = i2f(refs[k]);
             q[28 + k] = 0.0f;
@@ -204,7 +204,7 @@ inline void single_leaf_node4(const Box* leafBox, std::vector<Node4>& out) {
     float* q = out.back().q;
     for (int k = 0; k < 4; ++k) {
         const bool used = leafBox && k == 0;
-        for (int a = 0; a < 3; ++a) { q[4 * a + k] = used ? leafBox->lo[a] : NAN; q[12 + 4 * a + k] = used ? leafBox->hi[a] : NAN; }
+        for (int a = 0; a < 3; ++a) { q[8 * a + k] = used ? leafBox->lo[a] : NAN; q[8 * a + 4 + k] = used ? leafBox->hi[a] : NAN; }
         q[24 + k] = i2f(used ? ~0 : (int32_t)0x80000000);
         q[28 + k] = 0.0f;
     }

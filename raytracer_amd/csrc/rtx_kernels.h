@@ -33,7 +33,8 @@
 #define RTX_STAT_LEAF(b) (4 + (b))
 #define RTX_STAT_RAYS(b) (8 + (b))
 #define RTX_STAT_HITS(b) (12 + (b))
-#define RTX_STAT_WORDS 16
+#define RTX_STAT_PASSES(b) (16 + (b))   // traversal-loop passes of whole waves (lane-refill kernel, countStats only)
+#define RTX_STAT_WORDS 20
 
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
@@ -196,10 +197,10 @@ template <int MODE, bool COUNT>
 __global__ __launch_bounds__(RTX_BLOCK) void k_trace(DevScene sc, const float4* __restrict__ rqO, const float4* __restrict__ rqD,
                                                      float* __restrict__ hitT, int* __restrict__ hitLeaf,
                                                      uint32_t* __restrict__ ctrl, unsigned long long* __restrict__ stats,
-                                                     int countIdx, int workIdx) {
+                                                     uint32_t fixedCount, int countIdx, int workIdx) {
     int* stack = rtx_lds + threadIdx.x;
     uint32_t ic = 0, lc = 0;
-    const uint32_t count = ctrl[RTX_CTRL_COUNT(countIdx)];
+    const uint32_t count = countIdx == 0 ? fixedCount : ctrl[RTX_CTRL_COUNT(countIdx)];
     WorkIter<0> work(count);
     for (;;) {
         const uint32_t base = work.next(&ctrl[RTX_CTRL_WORK(workIdx)], count);
@@ -235,6 +236,9 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_trace(DevScene sc, const float4* 
 #define RTX_RESERVE 64u
 #endif
 #define RTX_IDLE ((int)0x80000002)
+#ifndef RTX_RAYS_PER_LANE
+#define RTX_RAYS_PER_LANE 4u
+#endif
 
 template <bool COUNT>
 __global__ __launch_bounds__(RTX_BLOCK) void k_trace_refill(DevScene sc, const float4* __restrict__ rqO, const float4* __restrict__ rqD,
@@ -251,19 +255,26 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_trace_refill(DevScene sc, const f
     const float4* __restrict__ nodes = sc.fast;
     const int root = sc.fastRoot;
     const uint32_t count = countIdx == 0 ? fixedCount : ctrl[RTX_CTRL_COUNT(countIdx)];
-    uint32_t ic = 0, lc = 0;
+    // A short queue is traced by fewer blocks: once the queue is drained every lane finishes the ray
+    // it holds without refill, so with one or two rays per lane most of the launch would run as that
+    // thinning tail. Blocks beyond count / (RTX_RAYS_PER_LANE * block size) leave at once.
+    if ((unsigned long long)blockIdx.x * (RTX_BLOCK * RTX_RAYS_PER_LANE) >= (unsigned long long)count && blockIdx.x > 0) return;
+    uint32_t ic = 0, lc = 0, wp = 0;
     uint32_t rcur = 0, rend = 0;          // wave-uniform: the wave's reserved run of the queue
     bool drained = false;                 // wave-uniform
     // per-lane ray state
     int cur = RTX_IDLE;
     uint32_t q = 0;
-    float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0, ix = 0, iy = 0, iz = 0;
+    float dx = 0, dy = 0, dz = 0;
+    WideRay w = wide_ray(0, 0, 0, 1, 1, 1);      // carries the origin too
     Hit best; best.t = INFINITY; best.leaf = -1; best.box = -1;
     float limit = INFINITY;
+    // Two nested loops, both wave-uniform: the outer one refills idle lanes, the inner one runs traversal
+    // passes until enough lanes are idle again. Inside the inner loop the ray (origin, direction,
+    // reciprocals, queue index) is loop-invariant, which keeps it in place in registers.
     for (;;) {
         const unsigned long long idle = __ballot(cur == RTX_IDLE);
-        const int nIdle = __popcll(idle);
-        if (nIdle == 64 && drained) break;
+        int nIdle = __popcll(idle);
         if (!drained && nIdle >= RTX_REFILL_MIN) {
             if (rcur >= rend) {
                 uint32_t base = 0;
@@ -279,11 +290,11 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_trace_refill(DevScene sc, const f
                 if (cur == RTX_IDLE && rank < take) {
                     q = rcur + rank;
                     const float4 o = rqO[q], d = rqD[q];
-                    ox = o.x; oy = o.y; oz = o.z; dx = d.x; dy = d.y; dz = d.z;
+                    dx = d.x; dy = d.y; dz = d.z;
                     if (d.w != 0.0f) {
                         hitLeaf[q] = RTX_INVALID_SLOT;     // slot outside the image, or a hole in a bounce queue
-                    } else if (lane_is_clean(ox, oy, oz, dx, dy, dz)) {
-                        ix = 1.0f / dx; iy = 1.0f / dy; iz = 1.0f / dz;
+                    } else if (lane_is_clean(o.x, o.y, o.z, dx, dy, dz)) {
+                        w = wide_ray(o.x, o.y, o.z, 1.0f / dx, 1.0f / dy, 1.0f / dz);
                         best.t = INFINITY; best.leaf = -1; best.box = -1; limit = INFINITY;
                         st.sp = 0; st.base = 0;
                         cur = root;
@@ -296,43 +307,45 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_trace_refill(DevScene sc, const f
             }
             continue;
         }
-        if (cur != RTX_IDLE) {
-            if (cur == RTX_NEED_POP) {
-                if (st.sp == 0) {
+        if (nIdle == 64) break;          // drained and nothing in flight
+        do {
+            if (COUNT) wp++;
+            if (cur != RTX_IDLE) {
+                bool finished = false;
+                if (cur == RTX_NEED_POP) {
+                    finished = true;
+                    while (st.sp > 0) {
+                        int ref; float tn;
+                        st.pop(ref, tn);
+                        if (!(tn > limit)) { cur = ref; finished = false; break; }
+                    }
+                }
+                if (finished) {
                     hitT[q] = best.t; hitLeaf[q] = best.leaf;
                     cur = RTX_IDLE;
-                    continue;
-                }
-                st.sp--;
-                int ref; float tn;
-                if (st.sp >= st.base) {
-                    const int slot = st.sp & (RTX_LDS_WINDOW - 1);
-                    ref = rtx_lds[st.lds + slot * st.stride]; tn = __int_as_float(rtx_lds[st.lds + (RTX_LDS_WINDOW + slot) * st.stride]);
+                } else if (cur >= 0) {
+                    if (COUNT) ic++;
+                    cur = wide_step<false>(nodes, cur, w, limit, st);
                 } else {
-                    const int2 e = st.spill[(long long)st.sp * st.spillStride];
-                    ref = e.x; tn = __int_as_float(e.y); st.base = st.sp;
+                    int leafIdx = ~cur, box;
+                    float t = intersect_leaf(sc.leaf, leafIdx, w.a.x, w.a.y, w.b.x, dx, dy, dz, box);
+                    if (COUNT) lc++;
+                    if (t > 0.01f && (t < best.t || (t == best.t && best.leaf >= 0 && box > best.box))) {
+                        best.t = t; best.leaf = leafIdx; best.box = box;
+                        limit = t + t * RTX_CULL_SLACK;
+                    }
+                    cur = RTX_NEED_POP;
                 }
-                if (tn > limit) continue;
-                cur = ref;
             }
-            if (cur >= 0) {
-                if (COUNT) ic++;
-                cur = wide_step(nodes, cur, ox, oy, oz, ix, iy, iz, limit, st);
-            } else {
-                int leafIdx = ~cur, box;
-                float t = intersect_leaf(sc.leaf, leafIdx, ox, oy, oz, dx, dy, dz, box);
-                if (COUNT) lc++;
-                if (t > 0.01f && (t < best.t || (t == best.t && best.leaf >= 0 && box > best.box))) {
-                    best.t = t; best.leaf = leafIdx; best.box = box;
-                    limit = t + t * RTX_CULL_SLACK;
-                }
-                cur = RTX_NEED_POP;
-            }
-        }
+            nIdle = __popcll(__ballot(cur == RTX_IDLE));
+        } while (drained ? nIdle < 64 : nIdle < RTX_REFILL_MIN);
     }
     if (COUNT) {
         ic = wave_sum(ic); lc = wave_sum(lc);
-        if (lane == 0) { atomicAdd(&stats[RTX_STAT_INNER(countIdx)], (unsigned long long)ic); atomicAdd(&stats[RTX_STAT_LEAF(countIdx)], (unsigned long long)lc); }
+        if (lane == 0) {
+            atomicAdd(&stats[RTX_STAT_INNER(countIdx)], (unsigned long long)ic); atomicAdd(&stats[RTX_STAT_LEAF(countIdx)], (unsigned long long)lc);
+            atomicAdd(&stats[RTX_STAT_PASSES(countIdx)], (unsigned long long)wp);
+        }
     }
 }
 

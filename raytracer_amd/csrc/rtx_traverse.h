@@ -187,6 +187,16 @@ struct LaneStack {
         rtx_lds[lds + (RTX_LDS_WINDOW + slot) * stride] = __float_as_int(tn);
         sp++;
     }
+    __device__ __forceinline__ void pop(int& ref, float& tn) {
+        sp--;
+        if (sp >= base) {
+            const int slot = sp & (RTX_LDS_WINDOW - 1);
+            ref = rtx_lds[lds + slot * stride]; tn = __int_as_float(rtx_lds[lds + (RTX_LDS_WINDOW + slot) * stride]);
+        } else {
+            const int2 e = spill[(long long)sp * spillStride];
+            ref = e.x; tn = __int_as_float(e.y); base = sp;
+        }
+    }
 };
 
 #define RTX_NEED_POP ((int)0x80000001)
@@ -194,20 +204,88 @@ struct LaneStack {
 #define RTX_CSWAP(ta, ra, tb, rb) { const bool s_ = tb < ta; const float tt_ = s_ ? ta : tb; const int rr_ = s_ ? ra : rb; \
                                     ta = s_ ? tb : ta; ra = s_ ? rb : ra; tb = tt_; rb = rr_; }
 
-// One step through a 4-wide node (rtx_build.h Node4: lo.x[4] lo.y[4] lo.z[4] hi.x[4] hi.y[4] hi.z[4] ref[4]):
-// tests the four child boxes, drops those that miss or start beyond `limit`, orders the rest by
-// entry distance, pushes all but the nearest (farthest first) and returns the nearest — or
-// RTX_NEED_POP when none is left. Empty slots hold NaN boxes: their distances compare false and never pass.
-__device__ __forceinline__ int wide_step(const float4* __restrict__ nodes, int cur, float ox, float oy, float oz,
-                                         float ix, float iy, float iz, float limit, LaneStack& st) {
-    const float4* N = nodes + (size_t)cur * 8;
-    const float4 lx = N[0], ly = N[1], lz = N[2], hx = N[3], hy = N[4], hz = N[5], rf = N[6];
-    float t0, t1, t2, t3;
-    const bool p0 = slab_test_clean(ox, oy, oz, ix, iy, iz, lx.x, ly.x, lz.x, hx.x, hy.x, hz.x, t0) && !(t0 > limit);
-    const bool p1 = slab_test_clean(ox, oy, oz, ix, iy, iz, lx.y, ly.y, lz.y, hx.y, hy.y, hz.y, t1) && !(t1 > limit);
-    const bool p2 = slab_test_clean(ox, oy, oz, ix, iy, iz, lx.z, ly.z, lz.z, hx.z, hy.z, hz.z, t2) && !(t2 > limit);
-    const bool p3 = slab_test_clean(ox, oy, oz, ix, iy, iz, lx.w, ly.w, lz.w, hx.w, hy.w, hz.w, t3) && !(t3 > limit);
-    int r0 = __float_as_int(rf.x), r1 = __float_as_int(rf.y), r2 = __float_as_int(rf.z), r3 = __float_as_int(rf.w);
+typedef float rtx_f4 __attribute__((ext_vector_type(4)));
+typedef float rtx_f2 __attribute__((ext_vector_type(2)));
+
+// The ray as the 4-wide step wants it: origin and reciprocal direction packed in three register pairs
+// (packed FP32 instructions broadcast either half of a pair), and for each axis the byte offset (0 or
+// 16) of the near plane inside a node's lo/hi block of that axis; the far plane sits at offset ^ 16
+// (rtx_build.h Node4: lo.x[4] hi.x[4] lo.y[4] hi.y[4] lo.z[4] hi.z[4] ref[4]). With min <= max on
+// every axis (checked by rtx_create) and no NaN, min((lo-o)*i, (hi-o)*i) IS the product taken with the
+// plane the sign of i selects — rounding is monotonic — so choosing the plane first gives the
+// reference's value with a third fewer instructions.
+struct WideRay {
+    rtx_f2 a, b, c;          // (ox, oy) (oz, ix) (iy, iz)
+    uint32_t nx, ny, nz;
+};
+__device__ __forceinline__ WideRay wide_ray(float ox, float oy, float oz, float ix, float iy, float iz) {
+    WideRay w;
+    w.a = rtx_f2{ox, oy}; w.b = rtx_f2{oz, ix}; w.c = rtx_f2{iy, iz};
+    w.nx = (__float_as_uint(ix) >> 27) & 16u;
+    w.ny = (__float_as_uint(iy) >> 27) & 16u;
+    w.nz = (__float_as_uint(iz) >> 27) & 16u;
+    return w;
+}
+
+// (v - o) * i on two children at once; o and i are the low (0) or high (1) half of a register pair.
+// v_pk_add_f32 with a negated operand and v_pk_mul_f32 round exactly like v_sub_f32 / v_mul_f32.
+template <int OH, int IH>
+__device__ __forceinline__ rtx_f2 pk_plane_distance(rtx_f2 v, rtx_f2 oPair, rtx_f2 iPair) {
+    rtx_f2 d, t;
+    if (OH == 0) asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(v), "v"(oPair));
+    else asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(v), "v"(oPair));
+    if (IH == 0) asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(d), "v"(iPair));
+    else asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(t) : "v"(d), "v"(iPair));
+    return t;
+}
+
+// One step through a 4-wide node: tests the four child boxes, drops those that miss or start beyond
+// `limit`, orders the rest by entry distance, pushes all but the nearest (farthest first) and returns
+// the nearest — or RTX_NEED_POP when none is left. Empty slots hold NaN boxes: their distances compare
+// false and never pass. Nodes are addressed as base + 32-bit byte offset (rtx_create keeps to the
+// reference topology for trees beyond 4 GiB of nodes).
+//
+// PACKED selects how the 24 plane distances are computed: as 12 + 12 packed FP32 instructions written
+// out by hand, or as plain scalar code. Same values either way; measured at 4K / 10 M triangles the
+// packed form is 4% faster in k_primary and 5% slower in the lane-refill kernel (where it costs
+// occupancy), so each caller picks.
+template <bool PACKED>
+__device__ __forceinline__ int wide_step(const float4* __restrict__ nodes, int cur, const WideRay& w, float limit, LaneStack& st) {
+    const char* base = (const char*)nodes;
+    const uint32_t off = (uint32_t)cur << 7;
+    const uint32_t ax = off | w.nx, ay = off | w.ny, az = off | w.nz;
+    const rtx_f4 nx = *(const rtx_f4*)(base + ax), fx = *(const rtx_f4*)(base + (ax ^ 16u));
+    const rtx_f4 ny = *(const rtx_f4*)(base + ay + 32), fy = *(const rtx_f4*)(base + (ay ^ 16u) + 32);
+    const rtx_f4 nz = *(const rtx_f4*)(base + az + 64), fz = *(const rtx_f4*)(base + (az ^ 16u) + 64);
+    const int4 rf = *(const int4*)(base + off + 96);
+    float t0, t1, t2, t3, f0, f1, f2, f3;
+    if (PACKED) {
+    const rtx_f2 tnx01 = pk_plane_distance<0, 1>(nx.xy, w.a, w.b), tnx23 = pk_plane_distance<0, 1>(nx.zw, w.a, w.b);
+    const rtx_f2 tny01 = pk_plane_distance<1, 0>(ny.xy, w.a, w.c), tny23 = pk_plane_distance<1, 0>(ny.zw, w.a, w.c);
+    const rtx_f2 tnz01 = pk_plane_distance<0, 1>(nz.xy, w.b, w.c), tnz23 = pk_plane_distance<0, 1>(nz.zw, w.b, w.c);
+    const rtx_f2 tfx01 = pk_plane_distance<0, 1>(fx.xy, w.a, w.b), tfx23 = pk_plane_distance<0, 1>(fx.zw, w.a, w.b);
+    const rtx_f2 tfy01 = pk_plane_distance<1, 0>(fy.xy, w.a, w.c), tfy23 = pk_plane_distance<1, 0>(fy.zw, w.a, w.c);
+    const rtx_f2 tfz01 = pk_plane_distance<0, 1>(fz.xy, w.b, w.c), tfz23 = pk_plane_distance<0, 1>(fz.zw, w.b, w.c);
+        t0 = fmaxf(tnx01.x, fmaxf(tny01.x, tnz01.x)); t1 = fmaxf(tnx01.y, fmaxf(tny01.y, tnz01.y));
+        t2 = fmaxf(tnx23.x, fmaxf(tny23.x, tnz23.x)); t3 = fmaxf(tnx23.y, fmaxf(tny23.y, tnz23.y));
+        f0 = fminf(tfx01.x, fminf(tfy01.x, tfz01.x)); f1 = fminf(tfx01.y, fminf(tfy01.y, tfz01.y));
+        f2 = fminf(tfx23.x, fminf(tfy23.x, tfz23.x)); f3 = fminf(tfx23.y, fminf(tfy23.y, tfz23.y));
+    } else {
+        const float ox = w.a.x, oy = w.a.y, oz = w.b.x, ix = w.b.y, iy = w.c.x, iz = w.c.y;
+        t0 = fmaxf((nx.x - ox) * ix, fmaxf((ny.x - oy) * iy, (nz.x - oz) * iz));
+        t1 = fmaxf((nx.y - ox) * ix, fmaxf((ny.y - oy) * iy, (nz.y - oz) * iz));
+        t2 = fmaxf((nx.z - ox) * ix, fmaxf((ny.z - oy) * iy, (nz.z - oz) * iz));
+        t3 = fmaxf((nx.w - ox) * ix, fmaxf((ny.w - oy) * iy, (nz.w - oz) * iz));
+        f0 = fminf((fx.x - ox) * ix, fminf((fy.x - oy) * iy, (fz.x - oz) * iz));
+        f1 = fminf((fx.y - ox) * ix, fminf((fy.y - oy) * iy, (fz.y - oz) * iz));
+        f2 = fminf((fx.z - ox) * ix, fminf((fy.z - oy) * iy, (fz.z - oz) * iz));
+        f3 = fminf((fx.w - ox) * ix, fminf((fy.w - oy) * iy, (fz.w - oz) * iz));
+    }
+    const bool p0 = t0 <= f0 && f0 > 0.0f && !(t0 > limit);
+    const bool p1 = t1 <= f1 && f1 > 0.0f && !(t1 > limit);
+    const bool p2 = t2 <= f2 && f2 > 0.0f && !(t2 > limit);
+    const bool p3 = t3 <= f3 && f3 > 0.0f && !(t3 > limit);
+    int r0 = rf.x, r1 = rf.y, r2 = rf.z, r3 = rf.w;
     t0 = p0 ? t0 : INFINITY; t1 = p1 ? t1 : INFINITY; t2 = p2 ? t2 : INFINITY; t3 = p3 ? t3 : INFINITY;
     r0 = p0 ? r0 : RTX_NEED_POP; r1 = p1 ? r1 : RTX_NEED_POP; r2 = p2 ? r2 : RTX_NEED_POP; r3 = p3 ? r3 : RTX_NEED_POP;
     const int n = (int)p0 + (int)p1 + (int)p2 + (int)p3;
@@ -230,6 +308,7 @@ __device__ __forceinline__ Hit traverse_fast(const DevScene& sc, float ox, float
                                              LaneStack st, uint32_t& innerCount, uint32_t& leafCount) {
     Hit best; best.t = INFINITY; best.leaf = -1; best.box = -1;
     const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;
+    const WideRay w = wide_ray(ox, oy, oz, ix, iy, iz);
     const float4* __restrict__ nodes = sc.fast;
     st.sp = 0; st.base = 0;
     int cur = sc.fastRoot;
@@ -251,7 +330,7 @@ __device__ __forceinline__ Hit traverse_fast(const DevScene& sc, float ox, float
         }
         if (cur >= 0) {
             if (COUNT) innerCount++;
-            cur = wide_step(nodes, cur, ox, oy, oz, ix, iy, iz, limit, st);
+            cur = wide_step<true>(nodes, cur, w, limit, st);
         } else {
             int leafIdx = ~cur, box;
             float t = intersect_leaf(sc.leaf, leafIdx, ox, oy, oz, dx, dy, dz, box);

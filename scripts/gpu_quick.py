@@ -17,3 +17,14 @@ for f in range(K):
 c = r.counters()
 km = [round(x / K, 3) for x in c.kernelMs]
 print("ms/frame", round(c.totalMs / K, 3), "Mrays/s", round(c.rays / (c.totalMs * 1e-3) / 1e6, 1), "kernels", km, flush=True)
+
+if os.environ.get("RTX_QUICK_COUNTS"):
+    rc = HIPShader(s, count_stats=True)
+    rc.frame_counter = 2; rc.Render(None)
+    cc = rc.counters()
+    rays = list(cc.raysPerBounce)
+    print("rays/bounce", rays, "hits/bounce", list(cc.hitsPerBounce))
+    print("node steps/ray", [round(cc.innerVisits[b] / max(rays[b], 1), 2) for b in range(4)],
+          "leaf tests/ray", [round(cc.leafTests[b] / max(rays[b], 1), 2) for b in range(4)],
+          "lane utilisation", [round((cc.innerVisits[b] + cc.leafTests[b]) / max(64 * cc.wavePasses[b], 1), 3) for b in range(4)],
+          "node-step share", [round(cc.innerVisits[b] / max(cc.innerVisits[b] + cc.leafTests[b], 1), 3) for b in range(4)], flush=True)

@@ -32,6 +32,8 @@ def main():
             per_dispatch[key] += float(r["Counter_Value"])
             names[r["Dispatch_Id"]] = short(r["Kernel_Name"])
         for (d, c), v in per_dispatch.items():
+            if c.startswith("GRBM_"):
+                v /= 8.0                   # reported summed over the 8 XCDs: a clock, not a sum
             ctr[names[d]][c].append(v)
     for k, cs in ctr.items():
         o = out.setdefault(k, {})
