@@ -162,7 +162,10 @@ def main():
         b = int(np.argmax(trace_ms))
         inner = cc.innerVisits[b] / args.steps
         leaf = cc.leafTests[b] / args.steps
-        algo_bytes = 64.0 * inner + 48.0 * leaf        # 64 B / inner visit, 48 B / leaf test
+        # bytes a traversal step reads: culled path = one 4-wide node, 7 x 16 B (6 plane vectors + 4 refs);
+        # exact path = one binary node of the reference topology, 64 B; a leaf test reads 48 B
+        node_bytes = 112.0 if args.traversal == "culled" else 64.0
+        algo_bytes = node_bytes * inner + 48.0 * leaf
         achieved = algo_bytes / (trace_ms[b] * 1e-3) / 1e9 if trace_ms[b] > 0 else 0.0
         traffic = None
         pmc = os.path.join(HERE, "profiles", "pmc_traffic.json")
@@ -172,13 +175,17 @@ def main():
             except Exception:
                 traffic = None
         all_rays = sum(cc.raysPerBounce)
-        roofline = {"bound": "hbm", "kernel": ["k_primary", "k_trace(bounce1)", "k_trace(bounce2)", "k_trace(bounce3)"][b],
+        roofline = {"bound": "hbm", "kernel": ["k_primary", "k_trace_refill(bounce1)", "k_trace_refill(bounce2)", "k_trace_refill(bounce3)"][b]
+                    if args.traversal == "culled" else ["k_primary", "k_trace(bounce1)", "k_trace(bounce2)", "k_trace(bounce3)"][b],
                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                     "traffic": traffic,
                     "algorithmic_bytes_per_launch": algo_bytes, "launch_ms": trace_ms[b],
-                    "inner_visits_per_ray": [cc.innerVisits[i] / max(1, cc.raysPerBounce[i]) for i in range(4)],
+                    "node_steps_per_ray": [cc.innerVisits[i] / max(1, cc.raysPerBounce[i]) for i in range(4)],
                     "leaf_tests_per_ray": [cc.leafTests[i] / max(1, cc.raysPerBounce[i]) for i in range(4)],
-                    "algorithmic_bytes_per_ray_all_trace": (64.0 * sum(cc.innerVisits) + 48.0 * sum(cc.leafTests)) / max(1, all_rays)}
+                    "node_bytes": node_bytes, "leaf_bytes": 48.0,
+                    "lane_utilisation": [(cc.innerVisits[i] + cc.leafTests[i]) / (64.0 * cc.wavePasses[i]) if cc.wavePasses[i] else None
+                                         for i in range(4)],
+                    "algorithmic_bytes_per_ray_all_trace": (node_bytes * sum(cc.innerVisits) + 48.0 * sum(cc.leafTests)) / max(1, all_rays)}
 
     # ---- CPU baseline: the oracle (CPU restatement of ThreadedShader) on a bounded sample ----
     cpu = None

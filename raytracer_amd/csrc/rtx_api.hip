@@ -304,8 +304,9 @@ void launch_trace(RtxRenderer* r, const float4* o, const float4* d, int countIdx
                            r->dHitT, r->dHitLeaf, r->dCtrl, r->dStats, fixedCount, countIdx, workIdx);
 }
 void dispatch_primary(RtxRenderer* r, const DevFrame& fr, int workIdx) {
-    // Bounce 0 is coherent (one 8x8 pixel block per wave): the fused generate+trace kernel measured
-    // faster (3.5 ms) than k_raygen + the refill kernel (4.1 ms) at 4K / 10 M triangles.
+    // Bounce 0 is coherent (one 8x8 pixel block per wave): it keeps one ray per lane per batch, fused with
+    // ray generation. Measured at 4K / 10 M triangles: fused 2.48 ms, k_raygen + k_trace 2.47 ms,
+    // k_raygen + the lane-refill kernel 3.7 ms (refill mixes rays of different blocks in a wave).
     if (r->mode == RTX_MODE_CULLED && getenv("RTX_SPLIT_PRIMARY")) {
         if (r->numSlots == 0) return;
         hipLaunchKernelGGL(k_raygen, dim3((r->numSlots + RTX_BLOCK - 1) / RTX_BLOCK), dim3(RTX_BLOCK), 0, r->stream, fr, r->dTiles,

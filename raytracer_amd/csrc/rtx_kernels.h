@@ -23,11 +23,16 @@
 #define RTX_MODE_LINEAR 2
 #define RTX_INVALID_SLOT (-2)
 
-// ctrl[] layout (uint32): [0..7] queue counts per bounce, [8..23] work counters per launch, [24..27] slow-list lengths
+// ctrl[] layout (uint32): [0..7] queue counts per bounce, [24..27] slow-list lengths, then the work counters:
+// one per (launch of the frame, queue segment), each on a 128-byte line of its own. Every queue is cut
+// into 8 contiguous segments and the blocks that share an XCD (blockIdx % 8, MI355X_MICROARCH.md
+// "Workgroup dispatch") draw from the same segment first, helping with the others once it is handed
+// out: an XCD's L2 then sees the rays of one image region at a time instead of a slice of every
+// region, and the counter atomics of a launch spread over 8 lines.
 #define RTX_CTRL_COUNT(b) (b)
-#define RTX_CTRL_WORK(k) (8 + (k))
 #define RTX_CTRL_SLOW(b) (24 + (b))     // rays of bounce b handed to the reference-topology kernel
-#define RTX_CTRL_WORDS 32
+#define RTX_CTRL_XWORK(launch, seg) (64 + ((launch) * 8 + (seg)) * 32)     // launch: 2*bounce trace, 2*bounce+1 shade
+#define RTX_CTRL_WORDS (64 + 8 * 8 * 32)
 // stats[] layout (uint64)
 #define RTX_STAT_INNER(b) (b)
 #define RTX_STAT_LEAF(b) (4 + (b))
@@ -43,32 +48,51 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 
 // Work distribution: a wave reserves a run of items with one device atomic and walks it 64 at a
 // time. One word takes ~88 atomics/us chip-wide (MI355X_MICROARCH.md "dequeue"), so reserving 64 at
-// a time caps a launch at ~5.6 G items/s (measured: the shade kernels ran 1.8x faster with longer
-// runs), while long runs unbalance the tail of the expensive trace launches (they are not
-// counter-bound: 64 at a time measured best there). Guided self-scheduling for the cheap items:
-// run length = remaining / (GUIDE x waves), between 64 and 4096; GUIDE = 0 means always 64.
-template <uint32_t GUIDE>
+// a time on one counter caps a launch at ~5.6 G items/s (measured: the shade kernels ran 1.8x faster
+// with longer runs), while long runs unbalance the tail of the expensive trace launches (64 at a time
+// measured best there). Guided self-scheduling for the cheap items: run length = what is left of the
+// segment / (GUIDE x waves drawing from it), between 64 and 4096; GUIDE = 0 means always 64.
+// Segments: see RTX_CTRL_XWORK.
+__device__ __forceinline__ uint32_t segment_length(uint32_t count) { return ((count + 7u) / 8u + 63u) & ~63u; }
+
+// SEGMENTED = false walks the queue front to back with the whole grid (segment 0 = the queue): k_shade
+// appends survivors in the order it consumes paths, and the next trace launch's segments are image
+// regions only if that order is the queue order.
+template <uint32_t GUIDE, bool SEGMENTED>
 struct WorkIter {
-    uint32_t cur, end, grab;     // wave-uniform
-    __device__ __forceinline__ static uint32_t run_length(uint32_t remaining) {
+    uint32_t cur, end, seen;          // wave-uniform: the reserved run, and how far the segment was seen handed out
+    uint32_t seg, tried, segLen, limit;
+    __device__ __forceinline__ uint32_t run_length(uint32_t remaining) const {
         if (GUIDE == 0) return 64u;
-        const uint32_t waves = gridDim.x * (RTX_BLOCK / 64u);
-        uint32_t g = (remaining / ((GUIDE ? GUIDE : 1u) * waves)) & ~63u;
+        const uint32_t waves = SEGMENTED ? (gridDim.x * (RTX_BLOCK / 64u) + 7u) / 8u : gridDim.x * (RTX_BLOCK / 64u);
+        const uint32_t g = (remaining / ((GUIDE ? GUIDE : 1u) * waves)) & ~63u;
         return g < 64u ? 64u : (g > 4096u ? 4096u : g);
     }
-    __device__ __forceinline__ explicit WorkIter(uint32_t limit) : cur(0), end(0), grab(run_length(limit)) {}
+    __device__ __forceinline__ explicit WorkIter(uint32_t limit_)
+        : cur(0), end(0), seen(0), seg(SEGMENTED ? (blockIdx.x & 7u) : 0u), tried(SEGMENTED ? 0u : 7u),
+          segLen(SEGMENTED ? segment_length(limit_) : ((limit_ + 63u) & ~63u)), limit(limit_) {}
     // base of this wave's next 64 items, or 0xffffffff when the queue is exhausted
-    __device__ __forceinline__ uint32_t next(uint32_t* counter, uint32_t limit) {
-        if (cur >= end) {
-            uint32_t base = 0;
-            if ((threadIdx.x & 63) == 0) base = atomicAdd(counter, grab);
-            cur = __builtin_amdgcn_readfirstlane(base);
-            end = cur + grab;
-            grab = run_length(limit > end ? limit - end : 0u);
+    __device__ __forceinline__ uint32_t next(uint32_t* ctrl, int launch) {
+        while (cur >= end) {
+            if (tried == 8u) return 0xffffffffu;
+            const uint32_t segStart = seg * segLen, segEnd = segStart + segLen < limit ? segStart + segLen : limit;
+            if (segStart < limit) {
+                const uint32_t grab = run_length(segEnd - segStart > seen ? segEnd - segStart - seen : 0u);
+                uint32_t base = 0;
+                if ((threadIdx.x & 63) == 0) base = atomicAdd(&ctrl[RTX_CTRL_XWORK(launch, seg)], grab);
+                base = __builtin_amdgcn_readfirstlane(base);
+                seen = base + grab;
+                if (base < segEnd - segStart) {
+                    cur = segStart + base;
+                    end = cur + grab < segEnd ? cur + grab : segEnd;
+                    break;
+                }
+            }
+            seg = (seg + 1u) & 7u; tried++; seen = 0;      // handed out: help with the next segment
         }
         const uint32_t b = cur;
         cur += 64u;
-        return b < limit ? b : 0xffffffffu;
+        return b;
     }
 };
 
@@ -168,9 +192,9 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_primary(DevScene sc, DevFrame fr,
     int* stack = rtx_lds + threadIdx.x;
     uint32_t ic = 0, lc = 0;
     const int countIdx = 0;
-    WorkIter<RTX_PRIMARY_GUIDE> work((uint32_t)fr.numSlots);
+    WorkIter<RTX_PRIMARY_GUIDE, true> work((uint32_t)fr.numSlots);
     for (;;) {
-        const uint32_t base = work.next(&ctrl[RTX_CTRL_WORK(workIdx)], (uint32_t)fr.numSlots);
+        const uint32_t base = work.next(ctrl, workIdx);
         if (base == 0xffffffffu) break;
         const uint32_t slot = base + (threadIdx.x & 63u);
         int x, y;
@@ -201,9 +225,9 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_trace(DevScene sc, const float4* 
     int* stack = rtx_lds + threadIdx.x;
     uint32_t ic = 0, lc = 0;
     const uint32_t count = countIdx == 0 ? fixedCount : ctrl[RTX_CTRL_COUNT(countIdx)];
-    WorkIter<0> work(count);
+    WorkIter<0, true> work(count);
     for (;;) {
-        const uint32_t base = work.next(&ctrl[RTX_CTRL_WORK(workIdx)], count);
+        const uint32_t base = work.next(ctrl, workIdx);
         if (base == 0xffffffffu) break;
         const uint32_t q = base + (threadIdx.x & 63u);
         if (q < count) {
@@ -261,6 +285,8 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_trace_refill(DevScene sc, const f
     if ((unsigned long long)blockIdx.x * (RTX_BLOCK * RTX_RAYS_PER_LANE) >= (unsigned long long)count && blockIdx.x > 0) return;
     uint32_t ic = 0, lc = 0, wp = 0;
     uint32_t rcur = 0, rend = 0;          // wave-uniform: the wave's reserved run of the queue
+    const uint32_t segLen = segment_length(count);
+    uint32_t seg = blockIdx.x & 7u, segsTried = 0;
     bool drained = false;                 // wave-uniform
     // per-lane ray state
     int cur = RTX_IDLE;
@@ -276,12 +302,18 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_trace_refill(DevScene sc, const f
         const unsigned long long idle = __ballot(cur == RTX_IDLE);
         int nIdle = __popcll(idle);
         if (!drained && nIdle >= RTX_REFILL_MIN) {
-            if (rcur >= rend) {
+            while (rcur >= rend && !drained) {
                 uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(&ctrl[RTX_CTRL_WORK(workIdx)], RTX_RESERVE);
-                rcur = __builtin_amdgcn_readfirstlane(base);
-                rend = rcur + RTX_RESERVE < count ? rcur + RTX_RESERVE : count;
-                if (rcur >= count) { drained = true; rend = rcur; }
+                if (lane == 0) base = atomicAdd(&ctrl[RTX_CTRL_XWORK(workIdx, seg)], RTX_RESERVE);
+                const uint32_t segStart = seg * segLen, segEnd = segStart + segLen < count ? segStart + segLen : count;
+                rcur = segStart + __builtin_amdgcn_readfirstlane(base);
+                rend = rcur + RTX_RESERVE < segEnd ? rcur + RTX_RESERVE : segEnd;
+                if (rcur >= segEnd || segStart >= count) {
+                    // this segment is handed out: help with the next one
+                    rend = rcur;
+                    seg = (seg + 1u) & 7u;
+                    if (++segsTried == 8u) drained = true;
+                }
             }
             if (!drained) {
                 const uint32_t avail = rend - rcur;
@@ -389,9 +421,9 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_shade(DevScene sc, DevFrame fr, c
     // single counter was the bottleneck of this kernel (same-address atomics retire at ~8 ns each).
     const uint32_t run = append_run_length(count);
     uint32_t outCur = 0, outEnd = 0;      // wave-uniform
-    WorkIter<2> work(count);
+    WorkIter<2, false> work(count);
     for (;;) {
-        const uint32_t base = work.next(&ctrl[RTX_CTRL_WORK(workIdx)], count);
+        const uint32_t base = work.next(ctrl, workIdx);
         if (base == 0xffffffffu) break;
         const uint32_t q = base + lane;
         bool active = q < count;
