@@ -625,7 +625,11 @@ int rtx_trace_rays(RtxRenderer* r, const float* origins, const float* directions
     if (e == hipSuccess) {
         float* saveT = r->dHitT; int* saveL = r->dHitLeaf; uint32_t* saveS = r->dSlow;
         r->dHitT = dT; r->dHitLeaf = dL; r->dSlow = dSlowTmp;
+        hipEvent_t t0 = nullptr, t1 = nullptr;
+        ok(hipEventCreate(&t0)); ok(hipEventCreate(&t1));
+        if (t0) ok(hipEventRecord(t0, r->stream));
         dispatch_trace(r, dO, dD, 1, 0, 0);
+        if (t1) ok(hipEventRecord(t1, r->stream));
         r->dHitT = saveT; r->dHitLeaf = saveL; r->dSlow = saveS;
         hipLaunchKernelGGL(k_probe_finish, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, r->stream, r->sc, r->linear ? 1 : 0,
                            dO, dD, dT, dL, (uint32_t)n, dI, dP, dN);
@@ -634,6 +638,10 @@ int rtx_trace_rays(RtxRenderer* r, const float* origins, const float* directions
         if (points) ok(hipMemcpyAsync(points, dP, n * sizeof(float4), hipMemcpyDeviceToHost, r->stream));
         if (normals) ok(hipMemcpyAsync(normals, dN, n * sizeof(float4), hipMemcpyDeviceToHost, r->stream));
         ok(hipStreamSynchronize(r->stream));
+        float ms = 0.0f;
+        if (t0 && t1 && hipEventElapsedTime(&ms, t0, t1) == hipSuccess) r->totals.lastTraceMs = ms;   // device time of the trace launches
+        if (t0) hipEventDestroy(t0);
+        if (t1) hipEventDestroy(t1);
     }
     void* ptrs[] = {dO, dD, dP, dN, dT, dL, dI, dSlowTmp};
     for (void* p : ptrs) if (p) hipFree(p);

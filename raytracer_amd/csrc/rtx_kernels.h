@@ -355,10 +355,14 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_trace_refill(DevScene sc, const f
                 if (finished) {
                     hitT[q] = best.t; hitLeaf[q] = best.leaf;
                     cur = RTX_IDLE;
-                } else if (cur >= 0) {
+                } else {
+                  if (cur >= 0) {
                     if (COUNT) ic++;
                     cur = wide_step<false>(nodes, cur, w, limit, st);
-                } else {
+                  }
+                  // not "else": a lane whose step ends at a leaf tests it in this same pass — the leaf
+                  // section runs in practically every pass anyway (some lane of the 64 is at a leaf)
+                  if (cur < 0 && cur != RTX_NEED_POP) {
                     int leafIdx = ~cur, box;
                     float t = intersect_leaf(sc.leaf, leafIdx, w.a.x, w.a.y, w.b.x, dx, dy, dz, box);
                     if (COUNT) lc++;
@@ -367,6 +371,7 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_trace_refill(DevScene sc, const f
                         limit = t + t * RTX_CULL_SLACK;
                     }
                     cur = RTX_NEED_POP;
+                  }
                 }
             }
             nIdle = __popcll(__ballot(cur == RTX_IDLE));

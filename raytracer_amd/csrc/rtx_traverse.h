@@ -331,7 +331,10 @@ __device__ __forceinline__ Hit traverse_fast(const DevScene& sc, float ox, float
         if (cur >= 0) {
             if (COUNT) innerCount++;
             cur = wide_step<true>(nodes, cur, w, limit, st);
-        } else {
+        }
+        // not "else": a lane whose step ends at a leaf tests it in this same pass (the leaf section
+        // runs in practically every pass anyway: some lane of the 64 is at a leaf)
+        if (cur < 0 && cur != RTX_NEED_POP) {
             int leafIdx = ~cur, box;
             float t = intersect_leaf(sc.leaf, leafIdx, ox, oy, oz, dx, dy, dz, box);
             if (COUNT) leafCount++;
