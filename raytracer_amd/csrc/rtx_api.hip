@@ -322,17 +322,22 @@ void dispatch_primary(RtxRenderer* r, const DevFrame& fr, int workIdx) {
 // fixedCount: queue length when it is known on the host (bounce 0 / probes), else read from ctrl[countIdx]
 void dispatch_trace(RtxRenderer* r, const float4* o, const float4* d, int countIdx, int workIdx, uint32_t fixedCount) {
     if (r->mode == RTX_MODE_CULLED) {
-        if (r->cfg.countStats) {
-            hipLaunchKernelGGL((k_trace_refill<true>), dim3(r->gridTrace), dim3(RTX_BLOCK), r->ldsTrace, r->stream, r->sc, o, d,
-                               r->dHitT, r->dHitLeaf, r->dCtrl, r->dStats, r->dSlow, fixedCount, countIdx, workIdx);
+        switch (countIdx * 2 + (r->cfg.countStats ? 1 : 0)) {
+#define RTX_REFILL_CASE(B, C)                                                                                              \
+        case (B) * 2 + ((C) ? 1 : 0):                                                                                       \
+            hipLaunchKernelGGL((k_trace_refill<C, B>), dim3(r->gridTrace), dim3(RTX_BLOCK), r->ldsTrace, r->stream, r->sc, \
+                               o, d, r->dHitT, r->dHitLeaf, r->dCtrl, r->dStats, r->dSlow, fixedCount, workIdx);            \
+            break;
+            RTX_REFILL_CASE(0, false) RTX_REFILL_CASE(0, true) RTX_REFILL_CASE(1, false) RTX_REFILL_CASE(1, true)
+            RTX_REFILL_CASE(2, false) RTX_REFILL_CASE(2, true) RTX_REFILL_CASE(3, false) RTX_REFILL_CASE(3, true)
+#undef RTX_REFILL_CASE
+        }
+        if (r->cfg.countStats)
             hipLaunchKernelGGL((k_trace_slow<true>), dim3(r->numCUs), dim3(RTX_BLOCK), r->ldsSlow, r->stream, r->sc, o, d,
                                r->dHitT, r->dHitLeaf, r->dCtrl, r->dStats, r->dSlow, countIdx);
-        } else {
-            hipLaunchKernelGGL((k_trace_refill<false>), dim3(r->gridTrace), dim3(RTX_BLOCK), r->ldsTrace, r->stream, r->sc, o, d,
-                               r->dHitT, r->dHitLeaf, r->dCtrl, r->dStats, r->dSlow, fixedCount, countIdx, workIdx);
+        else
             hipLaunchKernelGGL((k_trace_slow<false>), dim3(r->numCUs), dim3(RTX_BLOCK), r->ldsSlow, r->stream, r->sc, o, d,
                                r->dHitT, r->dHitLeaf, r->dCtrl, r->dStats, r->dSlow, countIdx);
-        }
         return;
     }
     if (r->mode == RTX_MODE_LINEAR) launch_trace<RTX_MODE_LINEAR>(r, o, d, countIdx, workIdx, fixedCount);

@@ -264,12 +264,14 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_trace(DevScene sc, const float4* 
 #define RTX_RAYS_PER_LANE 4u
 #endif
 
-template <bool COUNT>
+// BOUNCE (= the queue the launch reads) is a template parameter only so that profilers list the launches of
+// the three bounces — whose durations differ by 4x — under three kernel names.
+template <bool COUNT, int BOUNCE>
 __global__ __launch_bounds__(RTX_BLOCK) void k_trace_refill(DevScene sc, const float4* __restrict__ rqO, const float4* __restrict__ rqD,
                                                             float* __restrict__ hitT, int* __restrict__ hitLeaf,
                                                             uint32_t* __restrict__ ctrl, unsigned long long* __restrict__ stats,
-                                                            uint32_t* __restrict__ slowList, uint32_t fixedCount,
-                                                            int countIdx, int workIdx) {
+                                                            uint32_t* __restrict__ slowList, uint32_t fixedCount, int workIdx) {
+    const int countIdx = BOUNCE;
     const uint32_t lane = threadIdx.x & 63u;
     const unsigned long long laneLt = (1ull << lane) - 1ull;
     const long long nthreads = (long long)gridDim.x * RTX_BLOCK;

@@ -204,3 +204,92 @@ def test_empty_scene_renders_sky(libs):
     check_fb(px, want)
     assert (r.primary_hits(0) == -1).all()
     r.close()
+
+
+def _tiny_scene(kind):
+    from raytracer_amd.scene import HostScene, procedural_texture
+    s = HostScene(160, 96)
+    s.add_texture(procedural_texture(32, 3))
+    s.add_texture(procedural_texture(32, 4))
+    m = s.add_material("m", albedo=(0.8, 0.4, 0.2, 1.0), roughness=0.6, emmissionIntensity=0.5)
+    if kind == "one_sphere":
+        s.add_sphere((80, 48, 200), 60.0, m)
+    elif kind == "one_plane":            # two triangles: a wide node with two empty slots
+        s.add_plane((80, 20, 300), (0, 1, 0), (400, 400, 1), m)
+    else:                                # 2 + 1 + 12 leaves: partially filled wide nodes at several depths
+        s.add_plane((80, 10, 300), (0, 1, 0), (400, 400, 1), m)
+        s.add_sphere((60, 50, 220), 30.0, m)
+        s.add_cube((110, 40, 260), (30, 30, 30), m)
+    s.build_bvh(2)
+    cam = s.camera
+    from raytracer_amd.scene import look_at
+    cam.position.x, cam.position.y, cam.position.z = 80.0, 200.0, 0.0
+    look_at(cam, (80.0, 20.0, 300.0))
+    s.camera = cam
+    return s
+
+
+@pytest.mark.parametrize("kind", ["one_sphere", "one_plane", "mixed15"])
+def test_tiny_trees(libs, kind):
+    """One leaf (the wide tree is a single node holding it), two leaves, a handful: the 4-wide nodes'
+    empty slots must never report a hit."""
+    s = _tiny_scene(kind)
+    d, cam = s.desc(), s.camera
+    for trav in (_capi.TRAVERSE_CULLED, _capi.TRAVERSE_EXACT):
+        r = HIPShader(s, traversal=trav)
+        ids = r.primary_hits(0)
+        assert (ids == oracle.primary_hits(d, cam, 0)).all()
+        assert (ids >= 0).any()
+        px = np.zeros((d.height, d.width, 4), np.float32); want = np.zeros_like(px)
+        for f in range(2):
+            r.frame_counter = f
+            r.Render(px)
+            oracle.render(d, cam, f, want, 2)
+        check_fb(px, want)
+        r.close()
+
+
+def test_boxes_that_break_the_fast_path_preconditions_still_match(scene1):
+    """The culled path needs nested, well-formed boxes (DESIGN.md "Topology freedom"). A tree with an inner
+    box that does not contain its children, and one with an inverted (min > max) leaf box, must be rendered
+    exactly as the reference would render THOSE boxes: rtx_create falls back to the reference topology."""
+    from raytracer_amd.scene import scene_from_arrays
+    boxes0 = np.array(scene1.boxes, copy=True)
+    inner = np.flatnonzero((boxes0["objectID"] == -1) & (np.arange(len(boxes0)) > 0))
+    leaves = np.flatnonzero(boxes0["objectID"] != -1)
+    variants = []
+    b = boxes0.copy()                              # shrink a mid-tree inner box to a sliver of itself
+    k = inner[len(inner) // 3]
+    b["max"][k][:3] = b["min"][k][:3] + 0.25 * (b["max"][k][:3] - b["min"][k][:3])
+    variants.append(b)
+    b = boxes0.copy()                              # swap min and max of a leaf box on one axis
+    k = leaves[len(leaves) // 2]
+    b["min"][k][0], b["max"][k][0] = boxes0["max"][k][0], boxes0["min"][k][0]
+    variants.append(b)
+    for b in variants:
+        s = scene_from_arrays(scene1.width, scene1.height, scene1.objects, scene1.materials, b,
+                              scene1.texture_info, scene1.texture_data, scene1.camera)
+        d, cam = s.desc(), s.camera
+        r = HIPShader(s)                           # asks for the culled path
+        assert (r.primary_hits(0) == oracle.primary_hits(d, cam, 0)).all()
+        px = np.zeros((d.height, d.width, 4), np.float32); want = np.zeros_like(px)
+        r.Render(px); oracle.render(d, cam, 0, want, 8)
+        check_fb(px, want)
+        r.close()
+
+
+def test_wave_pass_counter_and_queue_holes(synth_small):
+    """countStats: lane utilisation of the refill kernel is a sane fraction; the queue holes that k_shade's
+    run reservation leaves are not counted as rays (ray counts equal the oracle's in the test above)."""
+    r = HIPShader(synth_small, count_stats=True)
+    for f in range(2):
+        r.frame_counter = f
+        r.Render(None)
+    c = r.counters()
+    for b in (1, 2, 3):
+        assert c.raysPerBounce[b] == c.hitsPerBounce[b - 1]
+        if c.raysPerBounce[b]:
+            assert c.wavePasses[b] > 0
+            work = c.innerVisits[b] + c.leafTests[b]
+            assert 0.0 < work / (64.0 * c.wavePasses[b]) <= 2.0      # a lane can do a node step and a leaf test in one pass
+    r.close()
