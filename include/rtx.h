@@ -142,7 +142,7 @@ typedef struct RtxCounters {
     uint64_t rays;            /* closest-hit queries issued (primary + bounce)             */
     uint64_t raysPerBounce[4];
     uint64_t hitsPerBounce[4];
-    uint64_t innerVisits[4];  /* inner-node records fetched, per bounce (countStats only)  */
+    uint64_t innerVisits[4];  /* node steps (4-wide nodes on the culled path, binary nodes otherwise), per bounce (countStats only) */
     uint64_t leafTests[4];    /* leaf primitives intersected, per bounce (countStats only) */
     double   lastFrameMs;     /* device time of the last rtx_render call (HIP events)      */
     double   lastTraceMs;     /* ... of which traversal kernels                            */
@@ -152,7 +152,8 @@ typedef struct RtxCounters {
      * renderer's stream): [0] primary, [1] shade0, [2] trace1, [3] shade1, ... [7] shade3 */
     double   kernelMs[8];
     uint64_t wavePasses[4];   /* traversal-loop passes of whole 64-lane waves, per bounce (countStats, culled bounce
-                                 launches only): (innerVisits + leafTests) / (64 * wavePasses) = lane utilisation */
+                                 launches only): (innerVisits + leafTests) / (64 * wavePasses) = work items per lane-pass
+                                 (a lane can do a node step and a leaf test in one pass) */
 } RtxCounters;
 
 typedef struct RtxRenderer RtxRenderer;

@@ -1,17 +1,19 @@
 // rtx_kernels.h — the per-frame kernels of the HIP backend.
 //
-// Frame pipeline (one stream, no host round trip inside a frame):
-//   k_primary            slot -> pixel, seed, jitter, primary ray, closest hit        (bounce 0)
-//   k_shade   (bounce b) sky or material shading, running-mean write-back of finished
-//                        paths, surviving paths compacted into the next ray queue
-//   k_trace   (bounce b) closest hit for the queued rays                              (b = 1..3)
-// Every kernel is a persistent grid whose waves pull 64-item chunks from a device
-// counter, so queue lengths never have to travel to the host. Surviving rays are
-// regrouped between bounces by wave ballot + prefix popcount (one atomic per wave),
-// so every trace launch runs on dense waves whatever the path mortality was.
-// Per-path state (ray, light, accumulator, seed) lives in SoA arrays indexed by
-// the path's slot; slots enumerate this rank's screen tiles in 8x8-pixel blocks,
-// one block per wave, so a wave's primary rays are spatially coherent.
+// Frame pipeline (one stream, no host round trip inside a frame; DESIGN.md §3):
+//   k_primary                 slot -> pixel, seed, jitter, primary ray, closest hit     (bounce 0)
+//   k_shade        (bounce b) sky or material shading, running-mean write-back of finished
+//                             paths, surviving paths appended to the next ray queue in
+//                             wave-private runs
+//   k_trace_refill (bounce b) closest hit for the queued rays on the 4-wide tree, idle lanes
+//                             refilled from the queue inside the traversal loop   (b = 1..3)
+//   k_trace_slow   (bounce b) the few rays whose slab arithmetic can produce NaN: reference
+//                             topology, reference semantics
+//   k_trace        (bounce b) EXACT / LINEAR modes: reference topology or the linear list
+// Every kernel is a persistent grid whose waves reserve work from device counters, so queue
+// lengths never have to travel to the host. Per-path state (light, accumulator, seed) lives
+// in SoA arrays indexed by the path's slot; slots enumerate this rank's screen tiles in
+// 8x8-pixel blocks, one block per wave, so a wave's primary rays are spatially coherent.
 #pragma once
 #include "rtx_device.h"
 #include "rtx_traverse.h"
