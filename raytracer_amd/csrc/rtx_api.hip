@@ -189,12 +189,8 @@ int flatten(const RtxSceneDesc& s, bool useBVH, bool wantFast, int nthreads, Fla
             for (int32_t k = 0; k < nLeaf; ++k) order[k] = (uint32_t)k;      // degenerate input: keep the reference topology
         } else {
             f.fast.reserve((size_t)nLeaf / 2);
-            rtxbuild::collapse4(bin.data(), binRoot, f.fast, f.fastDepth);
+            rtxbuild::collapse4(bin.data(), bin.size(), binRoot, f.fast, f.fastDepth);
             f.fastRoot = 0;
-            if (f.fast.size() > ((size_t)1 << 25)) {      // the kernels address nodes with 32-bit byte offsets (4 GiB)
-                f.fast.clear(); f.fast.shrink_to_fit();
-                for (int32_t k = 0; k < nLeaf; ++k) order[k] = (uint32_t)k;
-            }
         }
     } else if (wantFast && f.nested && nLeaf <= 1) {
         rtxbuild::Box b;
@@ -307,7 +303,7 @@ void dispatch_primary(RtxRenderer* r, const DevFrame& fr, int workIdx) {
     // Bounce 0 is coherent (one 8x8 pixel block per wave): it keeps one ray per lane per batch, fused with
     // ray generation. Measured at 4K / 10 M triangles: fused 2.48 ms, k_raygen + k_trace 2.47 ms,
     // k_raygen + the lane-refill kernel 3.7 ms (refill mixes rays of different blocks in a wave).
-    if (r->mode == RTX_MODE_CULLED && getenv("RTX_SPLIT_PRIMARY")) {
+    if (r->mode == RTX_MODE_CULLED && getenv("RTX_SPLIT_PRIMARY")) {      // experiment switch
         if (r->numSlots == 0) return;
         hipLaunchKernelGGL(k_raygen, dim3((r->numSlots + RTX_BLOCK - 1) / RTX_BLOCK), dim3(RTX_BLOCK), 0, r->stream, fr, r->dTiles,
                            r->dRqO[0], r->dRqD[0], r->dHitLeaf, r->dSeeds);
@@ -317,19 +313,22 @@ void dispatch_primary(RtxRenderer* r, const DevFrame& fr, int workIdx) {
     }
     if (r->mode == RTX_MODE_LINEAR) launch_primary<RTX_MODE_LINEAR>(r, fr, workIdx);
     else if (r->mode == RTX_MODE_EXACT) launch_primary<RTX_MODE_EXACT>(r, fr, workIdx);
+    else if (r->mode == RTX_MODE_CULLED_BIG) launch_primary<RTX_MODE_CULLED_BIG>(r, fr, workIdx);
     else launch_primary<RTX_MODE_CULLED>(r, fr, workIdx);
 }
 // fixedCount: queue length when it is known on the host (bounce 0 / probes), else read from ctrl[countIdx]
 void dispatch_trace(RtxRenderer* r, const float4* o, const float4* d, int countIdx, int workIdx, uint32_t fixedCount) {
-    if (r->mode == RTX_MODE_CULLED) {
-        switch (countIdx * 2 + (r->cfg.countStats ? 1 : 0)) {
-#define RTX_REFILL_CASE(B, C)                                                                                              \
-        case (B) * 2 + ((C) ? 1 : 0):                                                                                       \
-            hipLaunchKernelGGL((k_trace_refill<C, B>), dim3(r->gridTrace), dim3(RTX_BLOCK), r->ldsTrace, r->stream, r->sc, \
-                               o, d, r->dHitT, r->dHitLeaf, r->dCtrl, r->dStats, r->dSlow, fixedCount, workIdx);            \
+    if (r->mode == RTX_MODE_CULLED || r->mode == RTX_MODE_CULLED_BIG) {
+        const bool big = r->mode == RTX_MODE_CULLED_BIG;
+        switch (countIdx * 4 + (r->cfg.countStats ? 2 : 0) + (big ? 1 : 0)) {
+#define RTX_REFILL_CASE(B, C, G)                                                                                              \
+        case (B) * 4 + ((C) ? 2 : 0) + ((G) ? 1 : 0):                                                                          \
+            hipLaunchKernelGGL((k_trace_refill<C, B, G>), dim3(r->gridTrace), dim3(RTX_BLOCK), r->ldsTrace, r->stream, r->sc, \
+                               o, d, r->dHitT, r->dHitLeaf, r->dCtrl, r->dStats, r->dSlow, fixedCount, workIdx);               \
             break;
-            RTX_REFILL_CASE(0, false) RTX_REFILL_CASE(0, true) RTX_REFILL_CASE(1, false) RTX_REFILL_CASE(1, true)
-            RTX_REFILL_CASE(2, false) RTX_REFILL_CASE(2, true) RTX_REFILL_CASE(3, false) RTX_REFILL_CASE(3, true)
+#define RTX_REFILL_BOUNCE(B) RTX_REFILL_CASE(B, false, false) RTX_REFILL_CASE(B, false, true) RTX_REFILL_CASE(B, true, false) RTX_REFILL_CASE(B, true, true)
+            RTX_REFILL_BOUNCE(0) RTX_REFILL_BOUNCE(1) RTX_REFILL_BOUNCE(2) RTX_REFILL_BOUNCE(3)
+#undef RTX_REFILL_BOUNCE
 #undef RTX_REFILL_CASE
         }
         if (r->cfg.countStats)
@@ -413,6 +412,8 @@ int rtx_create(const RtxSceneDesc* scene, const RtxConfig* cfgIn, RtxRenderer** 
     r->linear = !useBVH;
     // distance culling needs boxes that contain their descendants; otherwise keep the reference's visit set
     r->mode = r->linear ? RTX_MODE_LINEAR : ((cfg.traversal == RTX_TRAVERSE_EXACT || !flat.nested || flat.fast.empty()) ? RTX_MODE_EXACT : RTX_MODE_CULLED);
+    if (r->mode == RTX_MODE_CULLED && (flat.fast.size() > ((size_t)1 << 25) || getenv("RTX_FORCE_BIG"))) r->mode = RTX_MODE_CULLED_BIG;
+    const bool culled = r->mode == RTX_MODE_CULLED || r->mode == RTX_MODE_CULLED_BIG;
     r->tileW = cfg.tileW; r->tileH = cfg.tileH;
 
 #define CREATE_TRY(expr) do { if (expr) { rtx_destroy(r); return 1; } } while (0)
@@ -460,7 +461,7 @@ int rtx_create(const RtxSceneDesc* scene, const RtxConfig* cfgIn, RtxRenderer** 
     r->sc.texInfo = r->dTexInfo; r->sc.texels = r->dTexels;
     r->sc.numTexelsPadded = (long long)scene->numTexels + RTX_TEX_PAD;
     r->sc.rootRef = flat.rootRef;
-    r->sc.fast = r->dFast;            // 4-wide nodes, 8 float4 each (NULL unless mode == RTX_MODE_CULLED)
+    r->sc.fast = r->dFast;            // 4-wide nodes, 8 float4 each (NULL unless the mode is CULLED / CULLED_BIG)
     r->sc.fastRoot = flat.fastRoot;
     r->sc.numLeaves = (int)(flat.leaf.size() / 4);
     r->sc.numInner = (int)(flat.inner.size() / 4);
@@ -500,12 +501,12 @@ int rtx_create(const RtxSceneDesc* scene, const RtxConfig* cfgIn, RtxRenderer** 
 
     // launch geometry: persistent grids sized by the LDS the traversal stack needs
     // culled path: a fixed window of the stack in LDS; exact path: the whole stack (refs only)
-    r->ldsTrace = r->linear ? 0 : (r->mode == RTX_MODE_CULLED ? (size_t)2 * RTX_LDS_WINDOW : (size_t)r->sc.stackDepth) * RTX_BLOCK * sizeof(int);
+    r->ldsTrace = r->linear ? 0 : (culled ? (size_t)2 * RTX_LDS_WINDOW : (size_t)r->sc.stackDepth) * RTX_BLOCK * sizeof(int);
 
     int blocksPerCU = 8;
     if (r->ldsTrace) blocksPerCU = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / r->ldsTrace));
     r->gridTrace = r->numCUs * blocksPerCU;
-    if (r->mode == RTX_MODE_CULLED) {
+    if (culled) {
         r->ldsSlow = (size_t)std::max(2, flat.maxDepth + 2) * RTX_BLOCK * sizeof(int);
         CREATE_HIP(hipMalloc((void**)&r->dSlow, nq * sizeof(uint32_t)));
         CREATE_HIP(hipMalloc((void**)&r->dSpill, (size_t)r->sc.stackDepth * r->gridTrace * RTX_BLOCK * sizeof(int2)));
@@ -516,7 +517,8 @@ int rtx_create(const RtxSceneDesc* scene, const RtxConfig* cfgIn, RtxRenderer** 
         fprintf(stderr, "[rtx] %d leaves, reference tree depth %d, own tree %s depth %d, stack %d entries, LDS %zu B/block, %d blocks/CU x %d CUs, mode %d\n",
                 r->sc.numLeaves, flat.maxDepth, flat.fast.empty() ? "absent" : "built", flat.fastDepth, r->sc.stackDepth, r->ldsTrace,
                 blocksPerCU, r->numCUs, r->mode),
-        fprintf(stderr, "[rtx] shade grid %d blocks (%d per CU), queue capacity %zu entries for %zu slots\n", r->gridShade, shadeBlocksPerCU, nq, n);
+        fprintf(stderr, "[rtx] shade grid %d blocks (%d per CU), queue capacity %zu entries for %zu slots, %zu wide nodes (%.2f per leaf)\n",
+                r->gridShade, shadeBlocksPerCU, nq, n, flat.fast.size(), r->sc.numLeaves ? (double)flat.fast.size() / r->sc.numLeaves : 0.0);
     *out = r;
     return 0;
 }

@@ -134,10 +134,20 @@ inline int32_t build_sah(const Box* prim, uint32_t n, uint32_t* order, Node* nod
 
 // ---- 4-wide collapse --------------------------------------------------------------
 // A traversal step costs the wave one dependent memory round trip plus the fixed overhead of the
-// pop / push / leaf sections, so the binary tree is folded into nodes of up to four children: a
-// node's children are replaced by their own children, largest box first, until four are held.
+// pop / push / leaf sections, so the binary tree is folded into nodes of up to four children.
 // Child boxes are copied unchanged (a leaf child keeps its exact leaf box), so the traversal
 // semantics do not change; only the number of steps does.
+//
+// Which binary nodes survive as wide nodes is chosen by dynamic programming over the binary tree
+// (the SAH-optimal collapse of Ylitie et al. 2017 restricted to 4 slots): the expected number of
+// steps of a random ray is proportional to the summed surface area of the surviving nodes (the leaf
+// term is the same for every collapse), so T[n][j] = the least such sum with which the subtree of n
+// can be presented to its parent as at most j children:
+//     T[n][1] = area(n) + split(n, 4)                     n survives, its own 4 slots filled optimally
+//     T[n][j] = min(T[n][1], split(n, j))                 or n dissolves into its parent's slots
+//     split(n, j) = min over k of T[left][k] + T[right][j - k];   T[leaf][.] = 0
+// Greedy "expand the largest child" leaves 3.0 children per node on the synthetic meshes; this gives
+// fuller nodes and fewer, smaller ones.
 struct Node4 {          // 128-byte record: lo.x[4] hi.x[4] lo.y[4] hi.y[4] lo.z[4] hi.z[4] ref[4] pad[4]
     float q[32];
 };
@@ -145,6 +155,7 @@ struct Node4 {          // 128-byte record: lo.x[4] hi.x[4] lo.y[4] hi.y[4] lo.z
 struct Collapser {
     const Node* bvh2;
     std::vector<Node4>& out;
+    std::vector<float> T;      // 4 per binary node: T[4 * n + j - 1]
     int maxDepth = 0;
 
     struct Child { Box box; int32_t ref; };
@@ -155,45 +166,69 @@ struct Collapser {
             c[k].ref = f2i(n.q[12 + k]);
         }
     }
+    float t(int32_t ref, int j) const { return ref < 0 ? 0.0f : T[4 * (size_t)ref + (size_t)(j - 1)]; }
+    // best way to hand `j` slots to the two children: returns the cost, k = slots of the left child
+    float split(const Child c[2], int j, int& k) const {
+        float best = INFINITY; k = 1;
+        for (int i = 1; i < j; ++i) { const float v = t(c[0].ref, i) + t(c[1].ref, j - i); if (v < best) { best = v; k = i; } }
+        return best;
+    }
+
+    // children point at higher indices than their parent (build_sah numbers nodes in pre-order)
+    void solve(size_t numNodes) {
+        T.assign(4 * numNodes, 0.0f);
+        for (size_t n = numNodes; n-- > 0;) {
+            Child c[2]; children_of(bvh2[n], c);
+            Box u = c[0].box; grow(u, c[1].box);
+            int k;
+            const float s2 = split(c, 2, k), s3 = split(c, 3, k), s4 = split(c, 4, k);
+            const float keep = (float)half_area(u) + s4;
+            T[4 * n + 0] = keep; T[4 * n + 1] = std::min(keep, s2); T[4 * n + 2] = std::min(keep, s3); T[4 * n + 3] = std::min(keep, s4);
+        }
+    }
+
+    // the children that subtree `ref` contributes when it may use up to j slots
+    void collect(const Child& me, int j, Child* slots, int& n) const {
+        if (me.ref < 0 || j == 1 || !(t(me.ref, j) < t(me.ref, 1))) { slots[n++] = me; return; }
+        Child c[2]; children_of(bvh2[me.ref], c);
+        int k; split(c, j, k);
+        collect(c[0], k, slots, n);
+        collect(c[1], j - k, slots, n);
+    }
 
     // emits the wide node for binary node `ref2` (>= 0) and returns its index
     int32_t emit(int32_t ref2, int depth) {
         maxDepth = std::max(maxDepth, depth);
-        Child c[4]; int n = 2;
-        children_of(bvh2[ref2], c);
-        while (n < 4) {
-            int pick = -1; double bestArea = -1.0;
-            for (int k = 0; k < n; ++k) if (c[k].ref >= 0) { double a = half_area(c[k].box); if (a > bestArea) { bestArea = a; pick = k; } }
-            if (pick < 0) break;
-            Child g[2];
-            children_of(bvh2[c[pick].ref], g);
-            c[pick] = g[0];
-            c[n++] = g[1];
-        }
+        Child c2[2]; children_of(bvh2[ref2], c2);
+        int k; split(c2, 4, k);
+        Child c[4]; int n = 0;
+        collect(c2[0], k, c, n);
+        collect(c2[1], 4 - k, c, n);
         const int32_t idx = (int32_t)out.size();
         out.emplace_back();
         int32_t refs[4];
-        for (int k = 0; k < 4; ++k) {
-            if (k < n) refs[k] = c[k].ref >= 0 ? emit(c[k].ref, depth + 1) : c[k].ref;
-            else refs[k] = (int32_t)0x80000000;                       // RTX_NO_CHILD
+        for (int i = 0; i < 4; ++i) {
+            if (i < n) refs[i] = c[i].ref >= 0 ? emit(c[i].ref, depth + 1) : c[i].ref;
+            else refs[i] = (int32_t)0x80000000;                       // RTX_NO_CHILD
         }
         float* q = out[idx].q;
-        for (int k = 0; k < 4; ++k) {
-            const bool used = k < n;
+        for (int i = 0; i < 4; ++i) {
+            const bool used = i < n;
             for (int a = 0; a < 3; ++a) {
-                q[8 * a + k] = used ? c[k].box.lo[a] : NAN;           // an empty slot never passes the slab test:
-                q[8 * a + 4 + k] = used ? c[k].box.hi[a] : NAN;       // every comparison with its NaN distances is false
+                q[8 * a + i] = used ? c[i].box.lo[a] : NAN;           // an empty slot never passes the slab test:
+                q[8 * a + 4 + i] = used ? c[i].box.hi[a] : NAN;       // every comparison with its NaN distances is false
             }
-            q[24 + k] = i2f(refs[k]);
-            q[28 + k] = 0.0f;
+            q[24 + i] = i2f(refs[i]);
+            q[28 + i] = 0.0f;
         }
         return idx;
     }
 };
 
-// Folds the binary tree rooted at inner node `root2` into 4-wide nodes (root = index 0).
-inline void collapse4(const Node* bvh2, int32_t root2, std::vector<Node4>& out, int& maxDepth) {
+// Folds the binary tree of `numNodes` inner nodes rooted at node `root2` into 4-wide nodes (root = index 0).
+inline void collapse4(const Node* bvh2, size_t numNodes, int32_t root2, std::vector<Node4>& out, int& maxDepth) {
     Collapser c{bvh2, out};
+    c.solve(numNodes);
     c.emit(root2, 0);
     maxDepth = c.maxDepth;
 }

@@ -23,6 +23,7 @@
 #define RTX_MODE_CULLED 0
 #define RTX_MODE_EXACT 1
 #define RTX_MODE_LINEAR 2
+#define RTX_MODE_CULLED_BIG 3     // CULLED over a tree of more than 2^25 wide nodes (64-bit node addresses)
 #define RTX_INVALID_SLOT (-2)
 
 // ctrl[] layout (uint32): [0..7] queue counts per bounce, [24..27] slow-list lengths, then the work counters:
@@ -135,7 +136,7 @@ __device__ __forceinline__ Hit closest_hit(const DevScene& sc, float ox, float o
     if (clean) {
         LaneStack st;
         st.lds = (int)threadIdx.x; st.stride = RTX_BLOCK; st.spill = sc.spill + gtid; st.spillStride = nthreads; st.sp = 0; st.base = 0;
-        h = traverse_fast<COUNT>(sc, ox, oy, oz, dx, dy, dz, st, ic, lc);
+        h = traverse_fast<COUNT, MODE == RTX_MODE_CULLED_BIG>(sc, ox, oy, oz, dx, dy, dz, st, ic, lc);
     }
     if (__any(!clean)) {
         if (!clean) h = traverse_bvh<true, COUNT>(sc, ox, oy, oz, dx, dy, dz, (int*)(sc.spill + gtid), (int)(2 * nthreads), ic, lc);
@@ -268,7 +269,7 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_trace(DevScene sc, const float4* 
 
 // BOUNCE (= the queue the launch reads) is a template parameter only so that profilers list the launches of
 // the three bounces — whose durations differ by 4x — under three kernel names.
-template <bool COUNT, int BOUNCE>
+template <bool COUNT, int BOUNCE, bool BIG>
 __global__ __launch_bounds__(RTX_BLOCK) void k_trace_refill(DevScene sc, const float4* __restrict__ rqO, const float4* __restrict__ rqD,
                                                             float* __restrict__ hitT, int* __restrict__ hitLeaf,
                                                             uint32_t* __restrict__ ctrl, unsigned long long* __restrict__ stats,
@@ -362,7 +363,7 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_trace_refill(DevScene sc, const f
                 } else {
                   if (cur >= 0) {
                     if (COUNT) ic++;
-                    cur = wide_step<false>(nodes, cur, w, limit, st);
+                    cur = wide_step<false, BIG>(nodes, cur, w, limit, st);
                   }
                   // not "else": a lane whose step ends at a leaf tests it in this same pass — the leaf
                   // section runs in practically every pass anyway (some lane of the 64 is at a leaf)

@@ -249,15 +249,28 @@ __device__ __forceinline__ rtx_f2 pk_plane_distance(rtx_f2 v, rtx_f2 oPair, rtx_
 // out by hand, or as plain scalar code. Same values either way; measured at 4K / 10 M triangles the
 // packed form is 4% faster in k_primary and 5% slower in the lane-refill kernel (where it costs
 // occupancy), so each caller picks.
-template <bool PACKED>
+//
+// BIG: trees beyond 2^25 nodes (4 GiB; ~100 M triangles) cannot use SGPR-base + 32-bit-offset addressing;
+// the same loads then take 64-bit lane addresses (a few more instructions and registers per step).
+template <bool PACKED, bool BIG>
 __device__ __forceinline__ int wide_step(const float4* __restrict__ nodes, int cur, const WideRay& w, float limit, LaneStack& st) {
-    const char* base = (const char*)nodes;
-    const uint32_t off = (uint32_t)cur << 7;
-    const uint32_t ax = off | w.nx, ay = off | w.ny, az = off | w.nz;
-    const rtx_f4 nx = *(const rtx_f4*)(base + ax), fx = *(const rtx_f4*)(base + (ax ^ 16u));
-    const rtx_f4 ny = *(const rtx_f4*)(base + ay + 32), fy = *(const rtx_f4*)(base + (ay ^ 16u) + 32);
-    const rtx_f4 nz = *(const rtx_f4*)(base + az + 64), fz = *(const rtx_f4*)(base + (az ^ 16u) + 64);
-    const int4 rf = *(const int4*)(base + off + 96);
+    rtx_f4 nx, fx, ny, fy, nz, fz; int4 rf;
+    if (BIG) {
+        const uintptr_t node = (uintptr_t)nodes + ((uintptr_t)(uint32_t)cur << 7);      // 128-byte aligned
+        const uintptr_t ax = node | w.nx, ay = node | w.ny, az = node | w.nz;
+        nx = *(const rtx_f4*)(ax); fx = *(const rtx_f4*)(ax ^ 16u);
+        ny = *(const rtx_f4*)(ay + 32); fy = *(const rtx_f4*)((ay ^ 16u) + 32);
+        nz = *(const rtx_f4*)(az + 64); fz = *(const rtx_f4*)((az ^ 16u) + 64);
+        rf = *(const int4*)(node + 96);
+    } else {
+        const char* base = (const char*)nodes;
+        const uint32_t off = (uint32_t)cur << 7;
+        const uint32_t ax = off | w.nx, ay = off | w.ny, az = off | w.nz;
+        nx = *(const rtx_f4*)(base + ax); fx = *(const rtx_f4*)(base + (ax ^ 16u));
+        ny = *(const rtx_f4*)(base + ay + 32); fy = *(const rtx_f4*)(base + (ay ^ 16u) + 32);
+        nz = *(const rtx_f4*)(base + az + 64); fz = *(const rtx_f4*)(base + (az ^ 16u) + 64);
+        rf = *(const int4*)(base + off + 96);
+    }
     float t0, t1, t2, t3, f0, f1, f2, f3;
     if (PACKED) {
     const rtx_f2 tnx01 = pk_plane_distance<0, 1>(nx.xy, w.a, w.b), tnx23 = pk_plane_distance<0, 1>(nx.zw, w.a, w.b);
@@ -303,7 +316,7 @@ __device__ __forceinline__ int wide_step(const float4* __restrict__ nodes, int c
 // near-first order, distance culling at push and at pop. One flat loop: every pass does at most one
 // pop, then one node step or one leaf test per lane — no nested per-lane loops for the wave to
 // serialise (nested while-while forms measured 1.8x slower here).
-template <bool COUNT>
+template <bool COUNT, bool BIG>
 __device__ __forceinline__ Hit traverse_fast(const DevScene& sc, float ox, float oy, float oz, float dx, float dy, float dz,
                                              LaneStack st, uint32_t& innerCount, uint32_t& leafCount) {
     Hit best; best.t = INFINITY; best.leaf = -1; best.box = -1;
@@ -330,7 +343,7 @@ __device__ __forceinline__ Hit traverse_fast(const DevScene& sc, float ox, float
         }
         if (cur >= 0) {
             if (COUNT) innerCount++;
-            cur = wide_step<true>(nodes, cur, w, limit, st);
+            cur = wide_step<true, BIG>(nodes, cur, w, limit, st);
         }
         // not "else": a lane whose step ends at a leaf tests it in this same pass (the leaf section
         // runs in practically every pass anyway: some lane of the 64 is at a leaf)
