@@ -47,6 +47,8 @@ def main():
     ap.add_argument("--traversal", default="culled", choices=["culled", "exact"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--frames-in-flight", type=int, default=0,
+                    help="RtxConfig.framesInFlight for the timed region: 0 = library default (3), 1 = strictly serial frames")
     ap.add_argument("--d2h", action="store_true", help="also time K frames with the host copy (reported in `extra`)")
     ap.add_argument("--orbit", action="store_true", help="-O camera: new camera + frameCounter=0 every frame (src/Main.cpp:68-82)")
     args = ap.parse_args()
@@ -77,7 +79,8 @@ def main():
     t_scene = time.time() - t0
     trav = _capi.TRAVERSE_EXACT if args.traversal == "exact" else _capi.TRAVERSE_CULLED
     t0 = time.time()
-    shader = HIPShader(scene, device=local_rank, rank=rank, world_size=world, traversal=trav)
+    shader = HIPShader(scene, device=local_rank, rank=rank, world_size=world, traversal=trav,
+                       frames_in_flight=args.frames_in_flight)
     t_create = time.time() - t0
     W, H = shader.width, shader.height
     gather = DeviceGather(shader, rank, world, torch.device("cuda", local_rank)) if world > 1 else None
@@ -129,7 +132,7 @@ def main():
     hits_per_bounce = [int(x) for x in c.hitsPerBounce]
 
     extra = {"scene_build_s": round(t_scene, 2), "rtx_create_s": round(t_create, 2),
-             "kernel_ms_per_frame": {"primary": kernel_ms[0], "shade0": kernel_ms[1], "trace1": kernel_ms[2],
+             "overlapped_kernel_ms_per_frame": {"primary": kernel_ms[0], "shade0": kernel_ms[1], "trace1": kernel_ms[2],
                                      "shade1": kernel_ms[3], "trace2": kernel_ms[4], "shade2": kernel_ms[5],
                                      "trace3": kernel_ms[6], "shade3": kernel_ms[7]},
              "device_ms_per_frame": c.totalMs / max(1, c.frames),
@@ -144,21 +147,31 @@ def main():
             shader.Render(px, cam)
         extra["ms_per_frame_with_d2h"] = (time.perf_counter() - t1) / args.steps * 1e3
 
-    # ---- roofline of the dominant kernel (rank 0): counted visits x record bytes / event time ----
+    # ---- roofline of the dominant kernel (rank 0) ---------------------------------------------------------
+    # The timed region keeps several frames in flight, so a launch there shares the machine with launches of
+    # other frames and its duration is not its own. The roofline pass renders the same frames again one at a
+    # time (framesInFlight = 1) with the counting instantiation of the kernels: node steps, leaf tests and the
+    # HIP-event duration then come from the very same launches (the counters cost ~3 %).
     roofline = None
     if rank == 0:
         shader.close()
-        counter = HIPShader(scene, device=local_rank, rank=rank, world_size=world, traversal=trav, count_stats=True)
-        for i in range(args.steps):
+        counter = HIPShader(scene, device=local_rank, rank=rank, world_size=world, traversal=trav, count_stats=True,
+                            frames_in_flight=1)
+        def count_step(i):
             if args.orbit:
-                orbit_camera(cam, 0.1 * (args.warmup + i), 0.1 * (args.warmup + i))
+                orbit_camera(cam, 0.1 * i, 0.1 * i)
                 counter.frame_counter = 0
             else:
-                counter.frame_counter = args.warmup + i
+                counter.frame_counter = i
             counter.Render(None, cam)
+        count_step(0)
+        counter.reset_counters()
+        for i in range(args.steps):
+            count_step(args.warmup + i)
         cc = counter.counters()
         counter.close()
-        trace_ms = [kernel_ms[0], kernel_ms[2], kernel_ms[4], kernel_ms[6]]
+        serial_ms = [x / max(1, cc.frames) for x in cc.kernelMs]
+        trace_ms = [serial_ms[0], serial_ms[2], serial_ms[4], serial_ms[6]]
         b = int(np.argmax(trace_ms))
         inner = cc.innerVisits[b] / args.steps
         leaf = cc.leafTests[b] / args.steps
@@ -178,19 +191,26 @@ def main():
             except Exception:
                 traffic = None
         all_rays = sum(cc.raysPerBounce)
-        roofline = {"bound": "hbm", "kernel": ["k_primary", "k_trace_refill(bounce1)", "k_trace_refill(bounce2)", "k_trace_refill(bounce3)"][b]
-                    if args.traversal == "culled" else ["k_primary", "k_trace(bounce1)", "k_trace(bounce2)", "k_trace(bounce3)"][b],
+        names = (["k_primary<CULLED, count>", "k_trace_refill<count, 1>", "k_trace_refill<count, 2>", "k_trace_refill<count, 3>"]
+                 if args.traversal == "culled" else ["k_primary<EXACT, count>", "k_trace<EXACT, count> bounce 1",
+                                                     "k_trace<EXACT, count> bounce 2", "k_trace<EXACT, count> bounce 3"])
+        roofline = {"bound": "hbm", "kernel": names[b],
                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                     "traffic": traffic,
                     "algorithmic_bytes_per_launch": algo_bytes, "launch_ms": trace_ms[b],
+                    "launch_ms_overlapped_in_timed_region": [kernel_ms[0], kernel_ms[2], kernel_ms[4], kernel_ms[6]][b],
                     "node_steps_per_ray": [cc.innerVisits[i] / max(1, cc.raysPerBounce[i]) for i in range(4)],
                     "leaf_tests_per_ray": [cc.leafTests[i] / max(1, cc.raysPerBounce[i]) for i in range(4)],
                     "bytes_per_node_step_survey": 64.0, "bytes_per_leaf_test": 48.0,
                     "requested_bytes_per_launch": requested_bytes, "requested_bytes_per_node_step": node_bytes,
                     "requested_gbs": requested_bytes / (trace_ms[b] * 1e-3) / 1e9 if trace_ms[b] > 0 else 0.0,
-                    "lane_utilisation": [(cc.innerVisits[i] + cc.leafTests[i]) / (64.0 * cc.wavePasses[i]) if cc.wavePasses[i] else None
-                                         for i in range(4)],
+                    "work_items_per_lane_pass": [(cc.innerVisits[i] + cc.leafTests[i]) / (64.0 * cc.wavePasses[i]) if cc.wavePasses[i] else None
+                                                 for i in range(4)],
                     "algorithmic_bytes_per_ray_all_trace": (64.0 * sum(cc.innerVisits) + 48.0 * sum(cc.leafTests)) / max(1, all_rays)}
+        extra["serial_kernel_ms_per_frame"] = {"primary": serial_ms[0], "shade0": serial_ms[1], "trace1": serial_ms[2],
+                                               "shade1": serial_ms[3], "trace2": serial_ms[4], "shade2": serial_ms[5],
+                                               "trace3": serial_ms[6], "shade3": serial_ms[7]}
+        extra["serial_device_ms_per_frame"] = cc.totalMs / max(1, cc.frames)
 
     # ---- CPU baseline: the oracle (CPU restatement of ThreadedShader) on a bounded sample ----
     cpu = None
@@ -222,7 +242,7 @@ def main():
                "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": args.workload, "triangles": ntri, "resolution": [W, H], "bounces": 4,
                           "spp_per_step": 1, "traversal": args.traversal, "partition": f"tiles64x32 round-robin x{world}",
-                          "camera": "orbit" if args.orbit else "fixed"},
+                          "camera": "orbit" if args.orbit else "fixed", "frames_in_flight": args.frames_in_flight or 3},
                "roofline": roofline, "cpu_baseline": cpu, "extra": extra}
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -134,7 +134,9 @@ typedef struct RtxConfig {
     int32_t tileH;         /*                             0 -> 32                    */
     int32_t traversal;     /* RTX_TRAVERSE_*                                         */
     int32_t countStats;    /* 1: count node/leaf visits per frame (slower kernels)   */
-    int32_t _pad;
+    int32_t framesInFlight;/* frames that may overlap on the device when rtx_render is called with
+                              pixels_rgba == NULL (each has its own stream and path state; the running
+                              mean is still updated in frame order); 0 -> 3, 1 = strictly serial */
 } RtxConfig;
 
 typedef struct RtxCounters {
@@ -147,7 +149,7 @@ typedef struct RtxCounters {
     double   lastFrameMs;     /* device time of the last rtx_render call (HIP events)      */
     double   lastTraceMs;     /* ... of which traversal kernels                            */
     double   lastShadeMs;     /* ... of which shading kernels                              */
-    double   totalMs;         /* sum of lastFrameMs over `frames`                          */
+    double   totalMs;         /* device time of `frames`, overlap of frames in flight counted once */
     /* per launch of the frame pipeline, summed over `frames` (HIP events on the
      * renderer's stream): [0] primary, [1] shade0, [2] trace1, [3] shade1, ... [7] shade3 */
     double   kernelMs[8];

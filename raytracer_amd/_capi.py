@@ -35,7 +35,7 @@ class SceneDesc(C.Structure):
 class Config(C.Structure):
     _fields_ = [("device", C.c_int32), ("rank", C.c_int32), ("worldSize", C.c_int32),
                 ("tileW", C.c_int32), ("tileH", C.c_int32), ("traversal", C.c_int32),
-                ("countStats", C.c_int32), ("_pad", C.c_int32)]
+                ("countStats", C.c_int32), ("framesInFlight", C.c_int32)]
 
 
 class Counters(C.Structure):

@@ -25,7 +25,8 @@ static int fail(const std::string& m) { g_err = m; return 1; }
         if (e_ != hipSuccess) return fail(std::string(#expr) + ": " + hipGetErrorString(e_)); \
     } while (0)
 
-static const int kRing = 4;       // frames whose timing events may still be pending
+static const int kRing = 8;       // frames whose timing events are kept; a frame's timing is read kLag frames later
+static const int kLag = 4;
 static const int kEvents = 10;    // start + one per kernel (8) + end
 
 struct RtxRenderer {
@@ -65,9 +66,28 @@ struct RtxRenderer {
     int gridTrace = 0, gridShade = 0;
     size_t ldsTrace = 0;
 
+    // Frames in flight: each has its own stream and its own per-path state / queues / work counters, so that
+    // the thin tails of one frame's launches overlap with the next frame's work. The fields above
+    // (stream, dRqO ... dCtrl, dSpill, dSlow, sc.spill) always alias the context selected by activate().
+    struct FrameCtx {
+        hipStream_t stream = nullptr;
+        float4 *dRqO[2] = {nullptr, nullptr}, *dRqD[2] = {nullptr, nullptr};
+        float* dHitT = nullptr; int* dHitLeaf = nullptr;
+        float4 *dLight = nullptr, *dAcc = nullptr;
+        uint32_t *dSeeds = nullptr, *dCtrl = nullptr, *dSlow = nullptr;
+        int2* dSpill = nullptr;
+        hipEvent_t resolved = nullptr;     // recorded after the context's latest k_resolve
+    };
+    std::vector<FrameCtx> ctx;
+    int active = 0;
+    int lastResolved = -1;               // context whose k_resolve was queued last
+    uint64_t frameSeq = 0;
+    uint64_t primaryRays = 0;            // rays of bounce 0 since the last reset (known on the host)
+
     // timing
     hipEvent_t ev[kRing][kEvents];
-    bool pending[kRing] = {false, false, false, false};
+    bool pending[kRing] = {};
+    int lastFinished = -1;           // ring slot of the frame whose timing was read last
     int ringPos = 0;
     RtxCounters totals{};
     std::vector<float> hostStage;   // D2H staging for worldSize > 1
@@ -263,6 +283,22 @@ DevFrame make_frame(const RtxRenderer* r, const RtxCamera* cam, uint32_t fc) {
     return fr;
 }
 
+void activate(RtxRenderer* r, int i) {
+    const RtxRenderer::FrameCtx& c = r->ctx[i];
+    r->active = i;
+    r->stream = c.stream;
+    for (int k = 0; k < 2; ++k) { r->dRqO[k] = c.dRqO[k]; r->dRqD[k] = c.dRqD[k]; }
+    r->dHitT = c.dHitT; r->dHitLeaf = c.dHitLeaf; r->dLight = c.dLight; r->dAcc = c.dAcc;
+    r->dSeeds = c.dSeeds; r->dCtrl = c.dCtrl; r->dSlow = c.dSlow; r->dSpill = c.dSpill;
+    r->sc.spill = c.dSpill;
+}
+
+// every frame in flight finished (the host-side entry points that touch the framebuffer start here)
+int sync_all(RtxRenderer* r) {
+    for (auto& c : r->ctx) if (c.stream) HIP_TRY(hipStreamSynchronize(c.stream));
+    return 0;
+}
+
 void finish_timing(RtxRenderer* r, int slot) {
     if (!r->pending[slot]) return;
     hipEventSynchronize(r->ev[slot][kEvents - 1]);
@@ -275,7 +311,13 @@ void finish_timing(RtxRenderer* r, int slot) {
         if (k & 1) shade += ms; else trace += ms;
     }
     r->totals.lastFrameMs = total; r->totals.lastTraceMs = trace; r->totals.lastShadeMs = shade;
-    r->totals.totalMs += total;
+    // totalMs adds up device time without counting overlap twice: a frame contributes what it ran past the
+    // end of the frame before it (frames in flight overlap; with framesInFlight = 1 this is the frame's own time)
+    float past = total;
+    if (r->lastFinished >= 0 && hipEventElapsedTime(&ms, r->ev[r->lastFinished][kEvents - 1], r->ev[slot][kEvents - 1]) == hipSuccess)
+        past = std::max(0.0f, std::min(total, ms));
+    r->totals.totalMs += past;
+    r->lastFinished = slot;
     r->pending[slot] = false;
 }
 
@@ -360,13 +402,17 @@ const char* rtx_version(void) { return "raytracer_amd HIP backend 0.1 (gfx950)";
 void rtx_destroy(RtxRenderer* r) {
     if (!r) return;
     hipSetDevice(r->device);
-    if (r->stream) hipStreamSynchronize(r->stream);
-    void* ptrs[] = {r->dSlow, r->dSpill, r->dFast, r->dInner, r->dLeaf, r->dShade, r->dMaterials, r->dTexInfo, r->dTexels, r->dTiles, r->dRqO[0], r->dRqO[1],
-                    r->dRqD[0], r->dRqD[1], r->dHitT, r->dHitLeaf, r->dLight, r->dAcc, r->dFb, r->dSeeds, r->dCtrl, r->dStats};
+    for (auto& c : r->ctx) {
+        if (c.stream) hipStreamSynchronize(c.stream);
+        void* own[] = {c.dRqO[0], c.dRqO[1], c.dRqD[0], c.dRqD[1], c.dHitT, c.dHitLeaf, c.dLight, c.dAcc, c.dSeeds, c.dCtrl, c.dSlow, c.dSpill};
+        for (void* p : own) if (p) hipFree(p);
+        if (c.resolved) hipEventDestroy(c.resolved);
+        if (c.stream) hipStreamDestroy(c.stream);
+    }
+    void* ptrs[] = {r->dFast, r->dInner, r->dLeaf, r->dShade, r->dMaterials, r->dTexInfo, r->dTexels, r->dTiles, r->dFb, r->dStats};
     for (void* p : ptrs) if (p) hipFree(p);
     for (int2* p : r->dTilesOfRank) if (p) hipFree(p);
     for (int i = 0; i < kRing; ++i) for (int k = 0; k < kEvents; ++k) if (r->ev[i][k]) hipEventDestroy(r->ev[i][k]);
-    if (r->stream) hipStreamDestroy(r->stream);
     delete r;
 }
 
@@ -423,7 +469,6 @@ int rtx_create(const RtxSceneDesc* scene, const RtxConfig* cfgIn, RtxRenderer** 
     hipDeviceProp_t prop;
     CREATE_HIP(hipGetDeviceProperties(&prop, r->device));
     r->numCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    CREATE_HIP(hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking));
     for (int i = 0; i < kRing; ++i) for (int k = 0; k < kEvents; ++k) CREATE_HIP(hipEventCreate(&r->ev[i][k]));
 
     // tiles: tile t (row-major over the tile grid) belongs to rank t % worldSize
@@ -483,16 +528,6 @@ int rtx_create(const RtxSceneDesc* scene, const RtxConfig* cfgIn, RtxRenderer** 
     // up to one unfinished run of holes per shade wave on top of the live rays)
     const size_t n = std::max<size_t>(r->numSlots, 64);
     const size_t nq = n + (size_t)r->gridShade * (RTX_BLOCK / 64) * RTX_MAX_RUN;
-    for (int k = 0; k < 2; ++k) {
-        CREATE_HIP(hipMalloc((void**)&r->dRqO[k], nq * sizeof(float4)));
-        CREATE_HIP(hipMalloc((void**)&r->dRqD[k], nq * sizeof(float4)));
-    }
-    CREATE_HIP(hipMalloc((void**)&r->dHitT, nq * sizeof(float)));
-    CREATE_HIP(hipMalloc((void**)&r->dHitLeaf, nq * sizeof(int)));
-    CREATE_HIP(hipMalloc((void**)&r->dLight, n * sizeof(float4)));
-    CREATE_HIP(hipMalloc((void**)&r->dAcc, n * sizeof(float4)));
-    CREATE_HIP(hipMalloc((void**)&r->dSeeds, n * sizeof(uint32_t)));
-    CREATE_HIP(hipMalloc((void**)&r->dCtrl, RTX_CTRL_WORDS * sizeof(uint32_t)));
     CREATE_HIP(hipMalloc((void**)&r->dStats, RTX_STAT_WORDS * sizeof(unsigned long long)));
     CREATE_HIP(hipMemset(r->dStats, 0, RTX_STAT_WORDS * sizeof(unsigned long long)));
     const size_t fbBytes = (size_t)r->width * r->height * sizeof(float4);
@@ -506,12 +541,30 @@ int rtx_create(const RtxSceneDesc* scene, const RtxConfig* cfgIn, RtxRenderer** 
     int blocksPerCU = 8;
     if (r->ldsTrace) blocksPerCU = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / r->ldsTrace));
     r->gridTrace = r->numCUs * blocksPerCU;
-    if (culled) {
-        r->ldsSlow = (size_t)std::max(2, flat.maxDepth + 2) * RTX_BLOCK * sizeof(int);
-        CREATE_HIP(hipMalloc((void**)&r->dSlow, nq * sizeof(uint32_t)));
-        CREATE_HIP(hipMalloc((void**)&r->dSpill, (size_t)r->sc.stackDepth * r->gridTrace * RTX_BLOCK * sizeof(int2)));
-        r->sc.spill = r->dSpill;
+    if (culled) r->ldsSlow = (size_t)std::max(2, flat.maxDepth + 2) * RTX_BLOCK * sizeof(int);
+    int depth = cfg.framesInFlight > 0 ? cfg.framesInFlight : 3;
+    if (const char* e = getenv("RTX_FRAMES_IN_FLIGHT")) depth = atoi(e);
+    depth = std::max(1, std::min(depth, kLag));
+    r->ctx.resize((size_t)depth);
+    for (auto& c : r->ctx) {
+        CREATE_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+        CREATE_HIP(hipEventCreateWithFlags(&c.resolved, hipEventDisableTiming));
+        for (int k = 0; k < 2; ++k) {
+            CREATE_HIP(hipMalloc((void**)&c.dRqO[k], nq * sizeof(float4)));
+            CREATE_HIP(hipMalloc((void**)&c.dRqD[k], nq * sizeof(float4)));
+        }
+        CREATE_HIP(hipMalloc((void**)&c.dHitT, nq * sizeof(float)));
+        CREATE_HIP(hipMalloc((void**)&c.dHitLeaf, nq * sizeof(int)));
+        CREATE_HIP(hipMalloc((void**)&c.dLight, n * sizeof(float4)));
+        CREATE_HIP(hipMalloc((void**)&c.dAcc, n * sizeof(float4)));
+        CREATE_HIP(hipMalloc((void**)&c.dSeeds, n * sizeof(uint32_t)));
+        CREATE_HIP(hipMalloc((void**)&c.dCtrl, RTX_CTRL_WORDS * sizeof(uint32_t)));
+        if (culled) {
+            CREATE_HIP(hipMalloc((void**)&c.dSlow, nq * sizeof(uint32_t)));
+            CREATE_HIP(hipMalloc((void**)&c.dSpill, (size_t)r->sc.stackDepth * r->gridTrace * RTX_BLOCK * sizeof(int2)));
+        }
     }
+    activate(r, 0);
     CREATE_HIP(hipDeviceSynchronize());
     if (getenv("RTX_VERBOSE"))
         fprintf(stderr, "[rtx] %d leaves, reference tree depth %d, own tree %s depth %d, stack %d entries, LDS %zu B/block, %d blocks/CU x %d CUs, mode %d\n",
@@ -525,9 +578,11 @@ int rtx_create(const RtxSceneDesc* scene, const RtxConfig* cfgIn, RtxRenderer** 
 
 static int render_frame(RtxRenderer* r, const RtxCamera* cam, uint32_t fc, bool primaryOnly) {
     HIP_TRY(hipSetDevice(r->device));
+    // frames take the contexts in turn; a context's stream orders a frame after the one that used it last
+    activate(r, (int)(r->frameSeq++ % r->ctx.size()));
     const int slot = r->ringPos;
     r->ringPos = (r->ringPos + 1) % kRing;
-    finish_timing(r, slot);
+    finish_timing(r, (slot + kRing - kLag) % kRing);     // the frame queued kLag frames ago has long finished
     const DevFrame fr = make_frame(r, cam, fc);
     HIP_TRY(hipMemsetAsync(r->dCtrl, 0, RTX_CTRL_WORDS * sizeof(uint32_t), r->stream));
     hipEvent_t* ev = r->ev[slot];
@@ -543,14 +598,22 @@ static int render_frame(RtxRenderer* r, const RtxCamera* cam, uint32_t fc, bool 
             }
             hipLaunchKernelGGL(k_shade, dim3(r->gridShade), dim3(RTX_BLOCK), 0, r->stream, r->sc, fr, r->dTiles, b, r->linear ? 1 : 0,
                                r->dRqO[in], r->dRqD[in], r->dHitT, r->dHitLeaf, r->dRqO[in ^ 1], r->dRqD[in ^ 1],
-                               r->dLight, r->dAcc, r->dSeeds, r->dFb, r->dCtrl, r->dStats, 2 * b + 1);
+                               r->dLight, r->dAcc, r->dSeeds, r->dCtrl, r->dStats, 2 * b + 1);
             HIP_TRY(hipEventRecord(ev[2 * b + 2], r->stream));
             in ^= 1;
         }
-        hipLaunchKernelGGL(k_fold_counts, dim3(1), dim3(64), 0, r->stream, r->dStats, (uint32_t)r->localPixels);
+        // the running mean takes the frames in order: this frame's resolve waits for the previous frame's
+        if (r->lastResolved >= 0 && r->lastResolved != r->active)
+            HIP_TRY(hipStreamWaitEvent(r->stream, r->ctx[r->lastResolved].resolved, 0));
+        if (r->numSlots)
+            hipLaunchKernelGGL(k_resolve, dim3((r->numSlots + RTX_BLOCK - 1) / RTX_BLOCK), dim3(RTX_BLOCK), 0, r->stream, fr, r->dTiles,
+                               r->dAcc, r->dFb);
+        HIP_TRY(hipEventRecord(r->ctx[r->active].resolved, r->stream));
+        r->lastResolved = r->active;
         HIP_TRY(hipEventRecord(ev[kEvents - 1], r->stream));
         r->pending[slot] = true;
         r->totals.frames++;
+        r->primaryRays += r->localPixels;
     }
     HIP_TRY(hipGetLastError());
     return 0;
@@ -610,6 +673,7 @@ int rtx_trace_rays(RtxRenderer* r, const float* origins, const float* directions
     if (n == 0) return 0;
     if (n > 0x7fffff00ull) return fail("too many rays");
     HIP_TRY(hipSetDevice(r->device));
+    if (sync_all(r)) return 1;
     float4 *dO = nullptr, *dD = nullptr, *dP = nullptr, *dN = nullptr; float* dT = nullptr; int *dL = nullptr, *dI = nullptr;
     uint32_t* dSlowTmp = nullptr;
     // the 4th direction lane is a flag inside the queues (1 = no ray); callers' 4th lane is "ignored"
@@ -659,6 +723,7 @@ int rtx_trace_rays(RtxRenderer* r, const float* origins, const float* directions
 int rtx_upload_pixels(RtxRenderer* r, const float* pixels) {
     if (!r || !pixels) return fail("NULL argument");
     HIP_TRY(hipSetDevice(r->device));
+    if (sync_all(r)) return 1;
     HIP_TRY(hipMemcpyAsync(r->dFb, pixels, (size_t)r->width * r->height * sizeof(float4), hipMemcpyHostToDevice, r->stream));
     HIP_TRY(hipStreamSynchronize(r->stream));
     return 0;
@@ -666,6 +731,7 @@ int rtx_upload_pixels(RtxRenderer* r, const float* pixels) {
 int rtx_download_pixels(RtxRenderer* r, float* pixels) {
     if (!r || !pixels) return fail("NULL argument");
     HIP_TRY(hipSetDevice(r->device));
+    if (sync_all(r)) return 1;
     HIP_TRY(hipMemcpyAsync(pixels, r->dFb, (size_t)r->width * r->height * sizeof(float4), hipMemcpyDeviceToHost, r->stream));
     HIP_TRY(hipStreamSynchronize(r->stream));
     return 0;
@@ -673,21 +739,29 @@ int rtx_download_pixels(RtxRenderer* r, float* pixels) {
 int rtx_clear_pixels(RtxRenderer* r) {
     if (!r) return fail("NULL argument");
     HIP_TRY(hipSetDevice(r->device));
+    if (sync_all(r)) return 1;
     HIP_TRY(hipMemsetAsync(r->dFb, 0, (size_t)r->width * r->height * sizeof(float4), r->stream));
+    HIP_TRY(hipStreamSynchronize(r->stream));      // frames on the other streams must not overtake the clear
     return 0;
 }
 
 int rtx_get_counters(RtxRenderer* r, RtxCounters* out) {
     if (!r || !out) return fail("NULL argument");
     HIP_TRY(hipSetDevice(r->device));
-    HIP_TRY(hipStreamSynchronize(r->stream));
+    if (sync_all(r)) return 1;
     // oldest pending frame first so that lastFrameMs ends up describing the newest one
     for (int i = 0; i < kRing; ++i) finish_timing(r, (r->ringPos + i) % kRing);
     unsigned long long st[RTX_STAT_WORDS];
     HIP_TRY(hipMemcpy(st, r->dStats, sizeof(st), hipMemcpyDeviceToHost));
     RtxCounters c = r->totals;
     c.rays = 0;
-    for (int b = 0; b < 4; ++b) { c.raysPerBounce[b] = st[RTX_STAT_RAYS(b)]; c.hitsPerBounce[b] = st[RTX_STAT_HITS(b)]; c.rays += st[RTX_STAT_RAYS(b)]; }
+    // rays of bounce 0 are known on the host; every hit before the last bounce continues (src/ThreadedShader.cpp:155-177),
+    // so the rays of bounce b+1 are the hits of bounce b (queue lengths would include the holes of k_shade's runs)
+    for (int b = 0; b < 4; ++b) {
+        c.hitsPerBounce[b] = st[RTX_STAT_HITS(b)];
+        c.raysPerBounce[b] = b == 0 ? r->primaryRays : st[RTX_STAT_HITS(b - 1)];
+        c.rays += c.raysPerBounce[b];
+    }
     for (int b = 0; b < 4; ++b) { c.innerVisits[b] = st[RTX_STAT_INNER(b)]; c.leafTests[b] = st[RTX_STAT_LEAF(b)]; c.wavePasses[b] = st[RTX_STAT_PASSES(b)]; }
     *out = c;
     return 0;
@@ -695,10 +769,11 @@ int rtx_get_counters(RtxRenderer* r, RtxCounters* out) {
 int rtx_reset_counters(RtxRenderer* r) {
     if (!r) return fail("NULL argument");
     HIP_TRY(hipSetDevice(r->device));
-    HIP_TRY(hipStreamSynchronize(r->stream));
+    if (sync_all(r)) return 1;
     for (int i = 0; i < kRing; ++i) finish_timing(r, i);
     HIP_TRY(hipMemset(r->dStats, 0, RTX_STAT_WORDS * sizeof(unsigned long long)));
     r->totals = RtxCounters{};
+    r->primaryRays = 0;
     return 0;
 }
 
@@ -713,6 +788,7 @@ uint64_t rtx_packed_floats(RtxRenderer* r, int32_t rank) {
 int rtx_pack_tiles(RtxRenderer* r, void* d_packed) {
     if (!r || !d_packed) return fail("NULL argument");
     HIP_TRY(hipSetDevice(r->device));
+    if (sync_all(r)) return 1;
     const uint64_t total = (uint64_t)r->localTiles.size() * r->tileW * r->tileH;
     if (total == 0) return 0;
     RtxCamera dummy{}; const DevFrame fr = make_frame(r, &dummy, 0);
@@ -726,6 +802,7 @@ int rtx_unpack_tiles(RtxRenderer* r, const void* d_packed, int32_t srcRank) {
     if (!r || !d_packed) return fail("NULL argument");
     if (srcRank < 0 || srcRank >= r->cfg.worldSize) return fail("srcRank out of range");
     HIP_TRY(hipSetDevice(r->device));
+    if (sync_all(r)) return 1;
     const uint64_t total = (uint64_t)r->tilesOfRank[srcRank].size() * r->tileW * r->tileH;
     if (total == 0) return 0;
     RtxCamera dummy{}; const DevFrame fr = make_frame(r, &dummy, 0);

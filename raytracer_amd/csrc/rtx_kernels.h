@@ -419,7 +419,7 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_shade(DevScene sc, DevFrame fr, c
                                                      const float* __restrict__ hitT, const int* __restrict__ hitLeaf,
                                                      float4* __restrict__ rqOout, float4* __restrict__ rqDout,
                                                      float4* __restrict__ lightArr, float4* __restrict__ accArr,
-                                                     uint32_t* __restrict__ seeds, float4* __restrict__ fb,
+                                                     uint32_t* __restrict__ seeds,
                                                      uint32_t* __restrict__ ctrl, unsigned long long* __restrict__ stats, int workIdx) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t count = bounce == 0 ? (uint32_t)fr.numSlots : ctrl[RTX_CTRL_COUNT(bounce)];
@@ -466,12 +466,9 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_shade(DevScene sc, DevFrame fr, c
                 finished = bounce == 3;
             }
             if (finished) {
-                int x, y;
-                slot_to_pixel(fr, tiles, (uint32_t)slot, x, y);
-                size_t pix = (size_t)y * (size_t)fr.width + (size_t)x;
-                F4 prev = from4(fb[pix]);
-                F4 res = lerp_color(prev, acc, fr.lerpScale);  // src/ThreadedShader.cpp:179-180
-                fb[pix] = make_float4(res.x, res.y, res.z, res.w);
+                // the path's colour waits in its slot for k_resolve: frames overlap on the device, and the
+                // running mean must be updated in frame order
+                accArr[slot] = make_float4(acc.x, acc.y, acc.z, acc.w);
             } else {
                 alive = true;
             }
@@ -503,14 +500,20 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_shade(DevScene sc, DevFrame fr, c
     if (lane == 0 && hits) atomicAdd(&stats[RTX_STAT_HITS(bounce)], (unsigned long long)hits);
 }
 
-// after the last shade: fold this frame's ray counts into the 64-bit totals. The queue lengths in
-// ctrl include the holes of k_shade's run reservation, so the rays of bounce b+1 are counted as what
-// they are: the hits of bounce b (every hit before the last bounce continues, src/ThreadedShader.cpp:155-177).
-__global__ void k_fold_counts(unsigned long long* __restrict__ stats, uint32_t primaryRays) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        stats[RTX_STAT_RAYS(0)] += primaryRays;
-        for (int b = 1; b < 4; ++b) stats[RTX_STAT_RAYS(b)] = stats[RTX_STAT_HITS(b - 1)];
-    }
+// After the last shade of a frame: pixels = Lerp(pixels, colour, 1 / (frameCounter + 1)) for every path of the
+// frame (src/ThreadedShader.cpp:179-180). A launch of its own because frames are pipelined (several in flight
+// on separate streams) while the running mean has to take them in order: the resolve launches
+// are chained by events, everything before them overlaps freely.
+__global__ __launch_bounds__(RTX_BLOCK) void k_resolve(DevFrame fr, const int2* __restrict__ tiles, const float4* __restrict__ accArr,
+                                                       float4* __restrict__ fb) {
+    const uint32_t slot = blockIdx.x * RTX_BLOCK + threadIdx.x;
+    if (slot >= (uint32_t)fr.numSlots) return;
+    int x, y;
+    if (!slot_to_pixel(fr, tiles, slot, x, y)) return;
+    const size_t pix = (size_t)y * (size_t)fr.width + (size_t)x;
+    const F4 prev = from4(fb[pix]);
+    const F4 res = lerp_color(prev, from4(accArr[slot]), fr.lerpScale);
+    fb[pix] = make_float4(res.x, res.y, res.z, res.w);
 }
 
 // ---- probes -------------------------------------------------------------------

@@ -16,7 +16,7 @@ from ._capi import Camera, Config, Counters, SceneDesc
 
 class HIPShader:
     def __init__(self, scene, device=0, rank=0, world_size=1, tile=(64, 32), traversal=_capi.TRAVERSE_CULLED,
-                 count_stats=False):
+                 count_stats=False, frames_in_flight=0):
         """`scene` is a raytracer_amd.scene.HostScene (or anything with .desc() and
         .camera); its arrays are read once, here (as src/CLShader.cpp:20-49 does)."""
         self._L = _capi.hip_lib()
@@ -25,7 +25,7 @@ class HIPShader:
         self.width, self.height = d.width, d.height
         self.frame_counter = 0                     # context->frameCounter
         cfg = Config(device=device, rank=rank, worldSize=world_size, tileW=tile[0], tileH=tile[1],
-                     traversal=traversal, countStats=1 if count_stats else 0)
+                     traversal=traversal, countStats=1 if count_stats else 0, framesInFlight=frames_in_flight)
         h = C.c_void_p()
         rc = self._L.rtx_create(C.byref(d), C.byref(cfg), C.byref(h))
         if rc != 0:

@@ -94,12 +94,18 @@ def main():
                 return None
             # MI355X_MICROARCH.md, HBM: on gfx950 FETCH_SIZE tallies 128-B requests at 64 B -> x2; WRITE_SIZE exact
             return 2.0 * o["fetch_bytes_raw"] + o.get("write_bytes_raw", 0.0)
-        names = {"k_primary": [k for k in out if k.startswith("k_primary") and "false" in k],
-                 "k_trace1": [k for k in out if k.startswith("k_trace") and "false" in k and k.endswith("#b1")],
-                 "k_trace2": [k for k in out if k.startswith("k_trace") and "false" in k and k.endswith("#b2")],
-                 "k_trace3": [k for k in out if k.startswith("k_trace") and "false" in k and k.endswith("#b3")]}
+        def targs(k):
+            return [a.strip() for a in k[k.index("<") + 1:k.index(">")].split(",")] if "<" in k else []
+        # the counting instantiations (COUNT = true): bench.py's roofline pass runs them one frame at a time
+        counting = lambda k: (k.startswith("k_primary") and targs(k)[1:2] == ["true"]) or \
+                             (k.startswith("k_trace") and targs(k)[:1] == ["true"]) or \
+                             (k.startswith("k_trace<") and targs(k)[1:2] == ["true"])
+        names = {"k_primary": [k for k in out if k.startswith("k_primary") and counting(k)],
+                 "k_trace1": [k for k in out if k.startswith("k_trace") and counting(k) and k.endswith("#b1")],
+                 "k_trace2": [k for k in out if k.startswith("k_trace") and counting(k) and k.endswith("#b2")],
+                 "k_trace3": [k for k in out if k.startswith("k_trace") and counting(k) and k.endswith("#b3")]}
         t = {"_note": "HBM-side bytes per launch = 2 x FETCH_SIZE KiB x 1024 + WRITE_SIZE KiB x 1024, separate rocprofv3 --pmc passes over "
-                      "`python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline` (scripts/prof_round.sh); the x2 is the guide's gfx950 "
+                      "`python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline` (scripts/prof_round.sh), launches of bench.py's roofline pass; the x2 is the guide's gfx950 "
                       "correction (128-B requests tallied at 64 B), exact for wide streams and an upper bound for this kernel's 16-B/lane "
                       "gathers; Infinity-Cache hits are counted, not excluded",
              workload: {n: (hbm(ks[0]) if ks else None) for n, ks in names.items()}}

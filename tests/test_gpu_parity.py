@@ -293,3 +293,31 @@ def test_wave_pass_counter_and_queue_holes(synth_small):
             work = c.innerVisits[b] + c.leafTests[b]
             assert 0.0 < work / (64.0 * c.wavePasses[b]) <= 2.0      # a lane can do a node step and a leaf test in one pass
     r.close()
+
+
+def test_frames_in_flight_keep_frame_order(scene2):
+    """rtx_render(pixels = NULL) only queues the frame; up to three frames overlap on the device, each on its own
+    stream with its own path state, while the running mean still takes them in order (k_resolve launches are
+    chained by events). The result must be the serial one, bit for bit, and the oracle's."""
+    d, cam = scene2.desc(), scene2.camera
+    frames = (0, 1, 2, 3, 4, 5, 6, 0, 1, 2, 3)          # includes a restart of the mean (frameCounter = 0)
+    out = {}
+    for fif in (1, 3):
+        r = HIPShader(scene2, frames_in_flight=fif)
+        for fc in frames:
+            r.frame_counter = fc
+            r.Render(None)
+        out[fif] = r.download()
+        c = r.counters()
+        assert c.frames == len(frames) and c.raysPerBounce[0] == len(frames) * d.width * d.height
+        # mixing queued and synchronous calls
+        px = np.zeros((d.height, d.width, 4), np.float32)
+        r.frame_counter = 4
+        r.Render(None); r.frame_counter = 5; r.Render(px)
+        out[(fif, "sync")] = px
+        r.close()
+    assert (out[1] == out[3]).all() and (out[(1, "sync")] == out[(3, "sync")]).all()
+    want = np.zeros_like(out[1])
+    for fc in frames:
+        oracle.render(d, cam, fc, want, 8)
+    check_fb(out[3], want)
