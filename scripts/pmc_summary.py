@@ -27,7 +27,9 @@ class BounceNamer:
         if k.startswith("k_primary") or k.startswith("k_raygen"):
             self.trace, self.shade = 0, 0
             return k
-        if k.startswith("k_trace_refill") or (k.startswith("k_trace<")):
+        if k.startswith("k_trace_refill"):
+            return f"{k}#b{k[k.index('<') + 1:k.index('>')].split(',')[1].strip()}"     # the bounce is a template argument
+        if k.startswith("k_trace<"):
             self.trace += 1
             return f"{k}#b{self.trace}"
         if k.startswith("k_shade"):
@@ -41,7 +43,8 @@ def main():
     root = sys.argv[1]
     out = {}
     for f in glob.glob(os.path.join(root, "trace", "**", "*_kernel_trace.csv"), recursive=True):
-        rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
+        # enqueue order (frames are queued one after the other even when they overlap on the device)
+        rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r.get("Dispatch_Id") or r["Start_Timestamp"]))
         namer = BounceNamer()
         dur = defaultdict(list)
         for r in rows:
