@@ -109,8 +109,9 @@ def main():
                  "k_trace3": [k for k in out if k.startswith("k_trace") and counting(k) and k.endswith("#b3")]}
         t = {"_note": "HBM-side bytes per launch = 2 x FETCH_SIZE KiB x 1024 + WRITE_SIZE KiB x 1024, separate rocprofv3 --pmc passes over "
                       "`python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline` (scripts/prof_round.sh), launches of bench.py's roofline pass; the x2 is the guide's gfx950 "
-                      "correction (128-B requests tallied at 64 B), exact for wide streams and an upper bound for this kernel's 16-B/lane "
-                      "gathers; Infinity-Cache hits are counted, not excluded",
+                      "correction (128-B requests tallied at 64 B), calibrated for this access pattern with tools/gather_ceiling (7 x 16 B "
+                      "from one scattered 128-B line per lane: one TCC_EA0_RDREQ and 64 B of FETCH_SIZE per line); Infinity-Cache hits "
+                      "are counted, not excluded",
              workload: {n: (hbm(ks[0]) if ks else None) for n, ks in names.items()}}
         open(sys.argv[3], "w").write(json.dumps(t, indent=1) + "\n")
     for k in sorted(out, key=lambda k: -out[k].get("total_ms", 0)):
