@@ -4,7 +4,7 @@
 // the traversal around it, as the calibration MI355X_MICROARCH.md asks for ("calibrate on a known byte
 // count in your own access pattern").
 //
-//   ./gather_ceiling [table_GiB=4] [loads_per_line=7] [iters=64]
+//   ./gather_ceiling [table_GiB=4] [loads_per_line=7] [iters=64]      (loads_per_line = 17: 7 loads, the first one waited for)
 // Every lane reads `loads_per_line` float4 from a pseudo-random line of the table per iteration, 4 lines in
 // flight per lane; lines are drawn by a multiplicative hash, so a 4 GiB table (32 Mi lines) is far beyond the
 // 4 MiB L2s and the 256 MiB Infinity Cache. Prints lines/s and the implied bytes/s at 64 and 128 B per line.
@@ -15,7 +15,7 @@
 
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 
-template <int LOADS>
+template <int LOADS, bool STAGED>
 __global__ __launch_bounds__(256) void k_gather(const float4* __restrict__ table, uint32_t lineMask, int iters, float* __restrict__ sink) {
     const uint32_t tid = blockIdx.x * 256 + threadIdx.x;
     uint32_t h = tid * 2654435761u + 12345u;
@@ -24,8 +24,16 @@ __global__ __launch_bounds__(256) void k_gather(const float4* __restrict__ table
         uint32_t line[4];
         for (int k = 0; k < 4; ++k) { h = h * 1664525u + 1013904223u; line[k] = (h >> 7) & lineMask; }
         float4 v[4][LOADS];
-        for (int k = 0; k < 4; ++k)
-            for (int j = 0; j < LOADS; ++j) v[k][j] = table[(size_t)line[k] * 8 + j];
+        if (STAGED) {
+            // first one load per line, wait for it, then the rest of the line (now L1 hits)
+            for (int k = 0; k < 4; ++k) v[k][0] = table[(size_t)line[k] * 8];
+            for (int k = 0; k < 4; ++k) asm volatile("" : "+v"(v[k][0].x));
+            for (int k = 0; k < 4; ++k)
+                for (int j = 1; j < LOADS; ++j) v[k][j] = table[(size_t)line[k] * 8 + j];
+        } else {
+            for (int k = 0; k < 4; ++k)
+                for (int j = 0; j < LOADS; ++j) v[k][j] = table[(size_t)line[k] * 8 + j];
+        }
         for (int k = 0; k < 4; ++k)
             for (int j = 0; j < LOADS; ++j) acc += v[k][j].x + v[k][j].w;
     }
@@ -52,10 +60,11 @@ int main(int argc, char** argv) {
     for (int rep = 0; rep < 4; ++rep) {
         CHECK(hipEventRecord(t0, 0));
         switch (loads) {
-        case 1: hipLaunchKernelGGL(k_gather<1>, dim3(blocks), dim3(256), 0, 0, table, (uint32_t)(lines - 1), iters, sink); break;
-        case 3: hipLaunchKernelGGL(k_gather<3>, dim3(blocks), dim3(256), 0, 0, table, (uint32_t)(lines - 1), iters, sink); break;
-        case 4: hipLaunchKernelGGL(k_gather<4>, dim3(blocks), dim3(256), 0, 0, table, (uint32_t)(lines - 1), iters, sink); break;
-        default: hipLaunchKernelGGL(k_gather<7>, dim3(blocks), dim3(256), 0, 0, table, (uint32_t)(lines - 1), iters, sink); break;
+        case 1: hipLaunchKernelGGL((k_gather<1, false>), dim3(blocks), dim3(256), 0, 0, table, (uint32_t)(lines - 1), iters, sink); break;
+        case 3: hipLaunchKernelGGL((k_gather<3, false>), dim3(blocks), dim3(256), 0, 0, table, (uint32_t)(lines - 1), iters, sink); break;
+        case 4: hipLaunchKernelGGL((k_gather<4, false>), dim3(blocks), dim3(256), 0, 0, table, (uint32_t)(lines - 1), iters, sink); break;
+        case 17: hipLaunchKernelGGL((k_gather<7, true>), dim3(blocks), dim3(256), 0, 0, table, (uint32_t)(lines - 1), iters, sink); break;
+        default: hipLaunchKernelGGL((k_gather<7, false>), dim3(blocks), dim3(256), 0, 0, table, (uint32_t)(lines - 1), iters, sink); break;
         }
         CHECK(hipEventRecord(t1, 0));
         CHECK(hipEventSynchronize(t1));
