@@ -63,7 +63,9 @@ struct RtxRenderer {
     uint32_t numSlots = 0;
 
     // launch geometry
-    int gridTrace = 0, gridShade = 0;
+    int gridTrace = 0, gridShade = 0;       // blocks that are resident at once: the largest grids ever launched
+    int launchTrace = 0, launchShade = 0;   // grids of the next launch (set_grids): smaller for short queues
+    uint32_t queueHint[4] = {0, 0, 0, 0};   // expected queue length per bounce, from the last frame whose counts arrived
     size_t ldsTrace = 0;
 
     // Frames in flight: each has its own stream and its own per-path state / queues / work counters, so that
@@ -77,6 +79,9 @@ struct RtxRenderer {
         uint32_t *dSeeds = nullptr, *dCtrl = nullptr, *dSlow = nullptr;
         int2* dSpill = nullptr;
         hipEvent_t resolved = nullptr;     // recorded after the context's latest k_resolve
+        uint32_t* hCounts = nullptr;       // pinned: the frame's queue lengths, copied back without a sync
+        hipEvent_t countsReady = nullptr;
+        bool countsPending = false;
     };
     std::vector<FrameCtx> ctx;
     int active = 0;
@@ -293,6 +298,19 @@ void activate(RtxRenderer* r, int i) {
     r->sc.spill = c.dSpill;
 }
 
+// A persistent grid costs ~70 ns per block to launch and drain whatever it finds to do (2048 blocks: 0.15 ms),
+// which is most of a launch over a short queue (a late bounce, a small image, a 1/8 tile share). The grid is
+// therefore sized by the expected queue length: one block per RTX_BLOCK * RTX_RAYS_PER_LANE rays, at least one
+// per CU. The expectation comes from the last frame whose queue lengths have arrived (copied back
+// asynchronously, never waited for); it only sizes the launch — the kernels distribute work dynamically
+// and are correct for any grid.
+void set_grids(RtxRenderer* r, uint32_t expected) {
+    const uint64_t perTraceBlock = (uint64_t)RTX_BLOCK * RTX_RAYS_PER_LANE, perShadeBlock = (uint64_t)RTX_BLOCK * 16u;
+    const uint64_t e = (uint64_t)expected + expected / 4u;
+    r->launchTrace = (int)std::max<uint64_t>((uint64_t)std::min(r->numCUs, r->gridTrace), std::min<uint64_t>((uint64_t)r->gridTrace, (e + perTraceBlock - 1) / perTraceBlock));
+    r->launchShade = (int)std::max<uint64_t>((uint64_t)std::min(r->numCUs / 2, r->gridShade), std::min<uint64_t>((uint64_t)r->gridShade, (e + perShadeBlock - 1) / perShadeBlock));
+}
+
 // every frame in flight finished (the host-side entry points that touch the framebuffer start here)
 int sync_all(RtxRenderer* r) {
     for (auto& c : r->ctx) if (c.stream) HIP_TRY(hipStreamSynchronize(c.stream));
@@ -326,19 +344,19 @@ void dispatch_trace(RtxRenderer* r, const float4* o, const float4* d, int countI
 template <int MODE>
 void launch_primary(RtxRenderer* r, const DevFrame& fr, int workIdx) {
     if (r->cfg.countStats)
-        hipLaunchKernelGGL((k_primary<MODE, true>), dim3(r->gridTrace), dim3(RTX_BLOCK), r->ldsTrace, r->stream, r->sc, fr, r->dTiles,
+        hipLaunchKernelGGL((k_primary<MODE, true>), dim3(r->launchTrace), dim3(RTX_BLOCK), r->ldsTrace, r->stream, r->sc, fr, r->dTiles,
                            r->dRqO[0], r->dRqD[0], r->dHitT, r->dHitLeaf, r->dSeeds, r->dCtrl, r->dStats, workIdx);
     else
-        hipLaunchKernelGGL((k_primary<MODE, false>), dim3(r->gridTrace), dim3(RTX_BLOCK), r->ldsTrace, r->stream, r->sc, fr, r->dTiles,
+        hipLaunchKernelGGL((k_primary<MODE, false>), dim3(r->launchTrace), dim3(RTX_BLOCK), r->ldsTrace, r->stream, r->sc, fr, r->dTiles,
                            r->dRqO[0], r->dRqD[0], r->dHitT, r->dHitLeaf, r->dSeeds, r->dCtrl, r->dStats, workIdx);
 }
 template <int MODE>
 void launch_trace(RtxRenderer* r, const float4* o, const float4* d, int countIdx, int workIdx, uint32_t fixedCount) {
     if (r->cfg.countStats)
-        hipLaunchKernelGGL((k_trace<MODE, true>), dim3(r->gridTrace), dim3(RTX_BLOCK), r->ldsTrace, r->stream, r->sc, o, d,
+        hipLaunchKernelGGL((k_trace<MODE, true>), dim3(r->launchTrace), dim3(RTX_BLOCK), r->ldsTrace, r->stream, r->sc, o, d,
                            r->dHitT, r->dHitLeaf, r->dCtrl, r->dStats, fixedCount, countIdx, workIdx);
     else
-        hipLaunchKernelGGL((k_trace<MODE, false>), dim3(r->gridTrace), dim3(RTX_BLOCK), r->ldsTrace, r->stream, r->sc, o, d,
+        hipLaunchKernelGGL((k_trace<MODE, false>), dim3(r->launchTrace), dim3(RTX_BLOCK), r->ldsTrace, r->stream, r->sc, o, d,
                            r->dHitT, r->dHitLeaf, r->dCtrl, r->dStats, fixedCount, countIdx, workIdx);
 }
 void dispatch_primary(RtxRenderer* r, const DevFrame& fr, int workIdx) {
@@ -365,7 +383,7 @@ void dispatch_trace(RtxRenderer* r, const float4* o, const float4* d, int countI
         switch (countIdx * 4 + (r->cfg.countStats ? 2 : 0) + (big ? 1 : 0)) {
 #define RTX_REFILL_CASE(B, C, G)                                                                                              \
         case (B) * 4 + ((C) ? 2 : 0) + ((G) ? 1 : 0):                                                                          \
-            hipLaunchKernelGGL((k_trace_refill<C, B, G>), dim3(r->gridTrace), dim3(RTX_BLOCK), r->ldsTrace, r->stream, r->sc, \
+            hipLaunchKernelGGL((k_trace_refill<C, B, G>), dim3(r->launchTrace), dim3(RTX_BLOCK), r->ldsTrace, r->stream, r->sc, \
                                o, d, r->dHitT, r->dHitLeaf, r->dCtrl, r->dStats, r->dSlow, fixedCount, workIdx);               \
             break;
 #define RTX_REFILL_BOUNCE(B) RTX_REFILL_CASE(B, false, false) RTX_REFILL_CASE(B, false, true) RTX_REFILL_CASE(B, true, false) RTX_REFILL_CASE(B, true, true)
@@ -407,6 +425,8 @@ void rtx_destroy(RtxRenderer* r) {
         void* own[] = {c.dRqO[0], c.dRqO[1], c.dRqD[0], c.dRqD[1], c.dHitT, c.dHitLeaf, c.dLight, c.dAcc, c.dSeeds, c.dCtrl, c.dSlow, c.dSpill};
         for (void* p : own) if (p) hipFree(p);
         if (c.resolved) hipEventDestroy(c.resolved);
+        if (c.countsReady) hipEventDestroy(c.countsReady);
+        if (c.hCounts) hipHostFree(c.hCounts);
         if (c.stream) hipStreamDestroy(c.stream);
     }
     void* ptrs[] = {r->dFast, r->dInner, r->dLeaf, r->dShade, r->dMaterials, r->dTexInfo, r->dTexels, r->dTiles, r->dFb, r->dStats};
@@ -549,6 +569,8 @@ int rtx_create(const RtxSceneDesc* scene, const RtxConfig* cfgIn, RtxRenderer** 
     for (auto& c : r->ctx) {
         CREATE_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
         CREATE_HIP(hipEventCreateWithFlags(&c.resolved, hipEventDisableTiming));
+        CREATE_HIP(hipEventCreateWithFlags(&c.countsReady, hipEventDisableTiming));
+        CREATE_HIP(hipHostMalloc((void**)&c.hCounts, 8 * sizeof(uint32_t), hipHostMallocDefault));
         for (int k = 0; k < 2; ++k) {
             CREATE_HIP(hipMalloc((void**)&c.dRqO[k], nq * sizeof(float4)));
             CREATE_HIP(hipMalloc((void**)&c.dRqD[k], nq * sizeof(float4)));
@@ -565,6 +587,8 @@ int rtx_create(const RtxSceneDesc* scene, const RtxConfig* cfgIn, RtxRenderer** 
         }
     }
     activate(r, 0);
+    for (int b = 0; b < 4; ++b) r->queueHint[b] = r->numSlots;
+    set_grids(r, r->numSlots);
     CREATE_HIP(hipDeviceSynchronize());
     if (getenv("RTX_VERBOSE"))
         fprintf(stderr, "[rtx] %d leaves, reference tree depth %d, own tree %s depth %d, stack %d entries, LDS %zu B/block, %d blocks/CU x %d CUs, mode %d\n",
@@ -584,19 +608,28 @@ static int render_frame(RtxRenderer* r, const RtxCamera* cam, uint32_t fc, bool 
     r->ringPos = (r->ringPos + 1) % kRing;
     finish_timing(r, (slot + kRing - kLag) % kRing);     // the frame queued kLag frames ago has long finished
     const DevFrame fr = make_frame(r, cam, fc);
+    {   // queue lengths of this context's previous frame, if they have arrived
+        RtxRenderer::FrameCtx& c = r->ctx[r->active];
+        if (c.countsPending && hipEventQuery(c.countsReady) == hipSuccess) {
+            for (int b = 1; b < 4; ++b) r->queueHint[b] = c.hCounts[b];
+            c.countsPending = false;
+        }
+    }
     HIP_TRY(hipMemsetAsync(r->dCtrl, 0, RTX_CTRL_WORDS * sizeof(uint32_t), r->stream));
     hipEvent_t* ev = r->ev[slot];
     HIP_TRY(hipEventRecord(ev[0], r->stream));
+    set_grids(r, r->numSlots);
     dispatch_primary(r, fr, 0);
     HIP_TRY(hipEventRecord(ev[1], r->stream));
     if (!primaryOnly) {
         int in = 0;
         for (int b = 0; b < 4; ++b) {
             if (b > 0) {
+                set_grids(r, std::min(r->queueHint[b], r->queueHint[b - 1]));
                 dispatch_trace(r, r->dRqO[in], r->dRqD[in], b, 2 * b, 0);
                 HIP_TRY(hipEventRecord(ev[2 * b + 1], r->stream));
             }
-            hipLaunchKernelGGL(k_shade, dim3(r->gridShade), dim3(RTX_BLOCK), 0, r->stream, r->sc, fr, r->dTiles, b, r->linear ? 1 : 0,
+            hipLaunchKernelGGL(k_shade, dim3(r->launchShade), dim3(RTX_BLOCK), 0, r->stream, r->sc, fr, r->dTiles, b, r->linear ? 1 : 0,
                                r->dRqO[in], r->dRqD[in], r->dHitT, r->dHitLeaf, r->dRqO[in ^ 1], r->dRqD[in ^ 1],
                                r->dLight, r->dAcc, r->dSeeds, r->dCtrl, r->dStats, 2 * b + 1);
             HIP_TRY(hipEventRecord(ev[2 * b + 2], r->stream));
@@ -610,6 +643,14 @@ static int render_frame(RtxRenderer* r, const RtxCamera* cam, uint32_t fc, bool 
                                r->dAcc, r->dFb);
         HIP_TRY(hipEventRecord(r->ctx[r->active].resolved, r->stream));
         r->lastResolved = r->active;
+        {
+            RtxRenderer::FrameCtx& c = r->ctx[r->active];
+            if (!c.countsPending) {
+                HIP_TRY(hipMemcpyAsync(c.hCounts, r->dCtrl, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, r->stream));
+                HIP_TRY(hipEventRecord(c.countsReady, r->stream));
+                c.countsPending = true;
+            }
+        }
         HIP_TRY(hipEventRecord(ev[kEvents - 1], r->stream));
         r->pending[slot] = true;
         r->totals.frames++;
@@ -699,6 +740,7 @@ int rtx_trace_rays(RtxRenderer* r, const float* origins, const float* directions
         hipEvent_t t0 = nullptr, t1 = nullptr;
         ok(hipEventCreate(&t0)); ok(hipEventCreate(&t1));
         if (t0) ok(hipEventRecord(t0, r->stream));
+        set_grids(r, (uint32_t)n);
         dispatch_trace(r, dO, dD, 1, 0, 0);
         if (t1) ok(hipEventRecord(t1, r->stream));
         r->dHitT = saveT; r->dHitLeaf = saveL; r->dSlow = saveS;

@@ -264,7 +264,7 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_trace(DevScene sc, const float4* 
 #endif
 #define RTX_IDLE ((int)0x80000002)
 #ifndef RTX_RAYS_PER_LANE
-#define RTX_RAYS_PER_LANE 4u
+#define RTX_RAYS_PER_LANE 2u
 #endif
 
 // BOUNCE (= the queue the launch reads) is a template parameter only so that profilers list the launches of
