@@ -214,7 +214,7 @@ int flatten(const RtxSceneDesc& s, bool useBVH, bool wantFast, int nthreads, Fla
             for (int32_t k = 0; k < nLeaf; ++k) order[k] = (uint32_t)k;      // degenerate input: keep the reference topology
         } else {
             f.fast.reserve((size_t)nLeaf / 2);
-            rtxbuild::collapse4(bin.data(), bin.size(), binRoot, f.fast, f.fastDepth);
+            rtxbuild::collapse4(bin.data(), bin.size(), binRoot, f.fast, f.fastDepth, nthreads);
             f.fastRoot = 0;
         }
     } else if (wantFast && f.nested && nLeaf <= 1) {

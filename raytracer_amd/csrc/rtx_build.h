@@ -19,6 +19,9 @@
 #include <cstring>
 #include <thread>
 #include <vector>
+#if defined(__SSE__)
+#include <xmmintrin.h>
+#endif
 
 namespace rtxbuild {
 
@@ -40,80 +43,238 @@ inline double half_area(const Box& b) {
 inline int32_t f2i(float f) { int32_t i; memcpy(&i, &f, 4); return i; }
 inline float i2f(int32_t i) { float f; memcpy(&f, &i, 4); return f; }
 
+// One binning pass per node covers the three axes at once, and the partition sweep collects both children's
+// centroid bounds on the way: two sweeps over a node's primitives per level (bin, partition) instead of five. Nodes above
+// 128 K primitives run both sweeps on all the threads they own (thread-local bins; partition through a
+// scratch array with per-chunk offsets), smaller subtrees are built one thread each.
+struct Item { float lo[3]; uint32_t id; float hi[3]; uint32_t pad;
+              Box box() const { Box b; for (int a = 0; a < 3; ++a) { b.lo[a] = lo[a]; b.hi[a] = hi[a]; } return b; } };     // 32 bytes: a primitive's box travels with its index, so that
+                                                          // every sweep over a node's primitives is a linear read
 struct SahBuilder {
-    const Box* prim;        // leaf boxes, indexed by primitive (= input leaf index)
-    uint32_t* order;        // permutation being partitioned in place; final = leaf order of the new tree
+    Item* items;            // partitioned in place; final order = leaf order of the new tree
     Node* nodes;            // n-1 inner records
-    int parallelDepth;
-    int maxDepth = 0;
+    Item* scratch;          // n entries, for the parallel partition
 
     static const int kBins = 16;
+    static const uint32_t kParallelNode = 1u << 17;
+    static const uint32_t kSweepNode = 16;
 
-    // builds the subtree over order[begin,end); returns its ref (>=0 inner index, <0 ~leafPosition)
-    int32_t build(uint32_t begin, uint32_t end, int32_t nodeIdx, int depth, Box& outBox, int& outDepth) {
-        const uint32_t n = end - begin;
-        if (n == 1) { outBox = prim[order[begin]]; outDepth = depth; return ~(int32_t)begin; }
-        // centroid bounds
-        float clo[3] = {INFINITY, INFINITY, INFINITY}, chi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    // a bin's box as two 4-float rows (lo.xyz _, hi.xyz _), the layout of an Item, so that growing it by an
+    // item is two packed min/max; the 4th lanes carry the item's id / padding bits and are never read
+    struct alignas(16) Bins {
+        float bb[3][kBins][8]; uint32_t cnt[3][kBins];
+        void clear() {
+            for (int a = 0; a < 3; ++a) for (int k = 0; k < kBins; ++k) {
+                for (int i = 0; i < 4; ++i) { bb[a][k][i] = INFINITY; bb[a][k][4 + i] = -INFINITY; }
+                cnt[a][k] = 0;
+            }
+        }
+        void merge(const Bins& o) {
+            for (int a = 0; a < 3; ++a) for (int k = 0; k < kBins; ++k) {
+                for (int i = 0; i < 3; ++i) { bb[a][k][i] = std::min(bb[a][k][i], o.bb[a][k][i]); bb[a][k][4 + i] = std::max(bb[a][k][4 + i], o.bb[a][k][4 + i]); }
+                cnt[a][k] += o.cnt[a][k];
+            }
+        }
+        Box box(int a, int k) const { Box b; for (int i = 0; i < 3; ++i) { b.lo[i] = bb[a][k][i]; b.hi[i] = bb[a][k][4 + i]; } return b; }
+        inline void add(int a, int k, const float* item8) {
+#if defined(__SSE__)
+            _mm_store_ps(bb[a][k], _mm_min_ps(_mm_load_ps(bb[a][k]), _mm_loadu_ps(item8)));
+            _mm_store_ps(bb[a][k] + 4, _mm_max_ps(_mm_load_ps(bb[a][k] + 4), _mm_loadu_ps(item8 + 4)));
+#else
+            for (int i = 0; i < 3; ++i) { bb[a][k][i] = std::min(bb[a][k][i], item8[i]); bb[a][k][4 + i] = std::max(bb[a][k][4 + i], item8[4 + i]); }
+#endif
+            cnt[a][k]++;
+        }
+    };
+    struct Split { float lo[3], scale[3]; bool valid[3]; };
+
+    static inline void centroid(const Box& b, float c[3]) { for (int a = 0; a < 3; ++a) c[a] = 0.5f * b.lo[a] + 0.5f * b.hi[a]; }
+    static inline void grow_centroid(Box& cb, const Item& b) {
+        for (int a = 0; a < 3; ++a) { const float c = 0.5f * b.lo[a] + 0.5f * b.hi[a]; cb.lo[a] = c < cb.lo[a] ? c : cb.lo[a]; cb.hi[a] = c > cb.hi[a] ? c : cb.hi[a]; }
+    }
+    static inline int bin_of(float c, float lo, float scale) {
+        int k = (int)((c - lo) * scale);
+        return k < 0 ? 0 : (k >= kBins ? kBins - 1 : k);
+    }
+    void bin_range(uint32_t begin, uint32_t end, const Split& sp, Bins& bins) const {
         for (uint32_t i = begin; i < end; ++i) {
-            const Box& b = prim[order[i]];
-            for (int a = 0; a < 3; ++a) { float c = 0.5f * b.lo[a] + 0.5f * b.hi[a]; clo[a] = std::min(clo[a], c); chi[a] = std::max(chi[a], c); }
-        }
-        int bestAxis = -1, bestBin = -1; double bestCost = INFINITY;
-        for (int a = 0; a < 3; ++a) {
-            const float ext = chi[a] - clo[a];
-            if (!(ext > 0.0f) || !std::isfinite(ext)) continue;
-            Box bb[kBins]; uint32_t cnt[kBins];
-            for (int k = 0; k < kBins; ++k) { bb[k] = empty_box(); cnt[k] = 0; }
-            const float scale = (float)kBins / ext;
-            for (uint32_t i = begin; i < end; ++i) {
-                const Box& b = prim[order[i]];
-                int k = (int)((0.5f * b.lo[a] + 0.5f * b.hi[a] - clo[a]) * scale);
-                k = k < 0 ? 0 : (k >= kBins ? kBins - 1 : k);
-                grow(bb[k], b); cnt[k]++;
-            }
-            double rightArea[kBins]; uint32_t rightCnt[kBins];
-            Box acc = empty_box(); uint32_t c = 0;
-            for (int k = kBins - 1; k > 0; --k) { grow(acc, bb[k]); c += cnt[k]; rightArea[k] = half_area(acc); rightCnt[k] = c; }
-            acc = empty_box(); c = 0;
-            for (int k = 0; k < kBins - 1; ++k) {
-                grow(acc, bb[k]); c += cnt[k];
-                if (c == 0 || rightCnt[k + 1] == 0) continue;
-                double cost = half_area(acc) * c + rightArea[k + 1] * rightCnt[k + 1];
-                if (cost < bestCost) { bestCost = cost; bestAxis = a; bestBin = k; }
+            const Item& it = items[i];
+            for (int a = 0; a < 3; ++a) {
+                if (!sp.valid[a]) continue;
+                bins.add(a, bin_of(0.5f * it.lo[a] + 0.5f * it.hi[a], sp.lo[a], sp.scale[a]), it.lo);
             }
         }
-        uint32_t mid;
-        if (bestAxis >= 0) {
-            const int a = bestAxis;
-            const float scale = (float)kBins / (chi[a] - clo[a]);
-            const float lo = clo[a];
-            uint32_t* m = std::partition(order + begin, order + end, [&](uint32_t p) {
-                const Box& b = prim[p];
-                int k = (int)((0.5f * b.lo[a] + 0.5f * b.hi[a] - lo) * scale);
-                k = k < 0 ? 0 : (k >= kBins ? kBins - 1 : k);
-                return k <= bestBin;
-            });
-            mid = (uint32_t)(m - order);
-            if (mid == begin || mid == end) mid = begin + n / 2;
-        } else {
-            mid = begin + n / 2;      // all centroids coincide (or are not finite): split by count
+    }
+    template <class F>
+    static void parallel_chunks(uint32_t begin, uint32_t end, int threads, F&& f) {
+        const uint32_t n = end - begin, per = (n + (uint32_t)threads - 1) / (uint32_t)threads;
+        std::vector<std::thread> pool;
+        for (int t = 1; t < threads; ++t) {
+            const uint32_t b = std::min(end, begin + (uint32_t)t * per), e = std::min(end, b + per);
+            pool.emplace_back([&f, t, b, e]() { f(t, b, e); });
         }
-        const uint32_t nl = mid - begin;
-        const int32_t leftIdx = nodeIdx + 1, rightIdx = nodeIdx + (int32_t)nl;   // left subtree has nl-1 inner nodes
-        Box bl, br; int dl = 0, dr = 0; int32_t rl, rr;
-        if (depth < parallelDepth && n > 8192) {
-            std::thread t([&]() { rl = build(begin, mid, leftIdx, depth + 1, bl, dl); });
-            rr = build(mid, end, rightIdx, depth + 1, br, dr);
-            t.join();
-        } else {
-            rl = build(begin, mid, leftIdx, depth + 1, bl, dl);
-            rr = build(mid, end, rightIdx, depth + 1, br, dr);
-        }
+        f(0, begin, std::min(end, begin + per));
+        for (auto& th : pool) th.join();
+    }
+
+    void write_node(int32_t nodeIdx, const Box& bl, const Box& br, int32_t rl, int32_t rr) {
         float* q = nodes[nodeIdx].q;
         q[0] = bl.lo[0]; q[1] = bl.lo[1]; q[2] = bl.lo[2]; q[3] = bl.hi[0]; q[4] = bl.hi[1]; q[5] = bl.hi[2];
         q[6] = br.lo[0]; q[7] = br.lo[1]; q[8] = br.lo[2]; q[9] = br.hi[0]; q[10] = br.hi[1]; q[11] = br.hi[2];
         q[12] = i2f(rl); q[13] = i2f(rr); q[14] = 0; q[15] = 0;
+    }
+
+    // Subtrees of at most kSweepNode primitives — 15 of every 16 nodes of the tree — are split by an exact
+    // sweep: per axis, sort by centroid, evaluate all n-1 split positions. Cheaper than clearing and
+    // evaluating 3 x 16 bins for a handful of primitives, and the best split there is.
+    int32_t build_small(uint32_t begin, uint32_t end, int32_t nodeIdx, int depth, Box& outBox, int& outDepth) {
+        const uint32_t n = end - begin;
+        if (n == 1) { outBox = items[begin].box(); outDepth = depth; return ~(int32_t)begin; }
+        uint8_t idx[3][kSweepNode]; int bestAxis = -1; uint32_t bestPos = 0; double bestCost = INFINITY;
+        for (int a = 0; a < 3; ++a) {
+            float key[kSweepNode];
+            for (uint32_t i = 0; i < n; ++i) {                         // insertion sort by centroid
+                const float c = 0.5f * items[begin + i].lo[a] + 0.5f * items[begin + i].hi[a];
+                uint32_t j = i;
+                while (j > 0 && key[j - 1] > c) { key[j] = key[j - 1]; idx[a][j] = idx[a][j - 1]; --j; }
+                key[j] = c; idx[a][j] = (uint8_t)i;
+            }
+            double rightArea[kSweepNode];
+            Box acc = empty_box();
+            for (uint32_t i = n - 1; i > 0; --i) { grow(acc, items[begin + idx[a][i]].box()); rightArea[i] = half_area(acc); }
+            acc = empty_box();
+            for (uint32_t i = 0; i + 1 < n; ++i) {
+                grow(acc, items[begin + idx[a][i]].box());
+                const double cost = half_area(acc) * (i + 1) + rightArea[i + 1] * (n - i - 1);
+                // equal costs (identical boxes): the split nearest the middle, not a chain
+                const uint32_t off = i + 1 > n / 2 ? i + 1 - n / 2 : n / 2 - (i + 1), bestOff = bestPos > n / 2 ? bestPos - n / 2 : n / 2 - bestPos;
+                if (cost < bestCost || (cost == bestCost && off < bestOff)) { bestCost = cost; bestAxis = a; bestPos = i + 1; }
+            }
+        }
+        if (bestAxis < 0) { bestAxis = 0; bestPos = n / 2; }           // non-finite areas: split by count
+        Item tmp[kSweepNode];
+        for (uint32_t i = 0; i < n; ++i) tmp[i] = items[begin + idx[bestAxis][i]];
+        for (uint32_t i = 0; i < n; ++i) items[begin + i] = tmp[i];
+        const uint32_t mid = begin + bestPos;
+        Box bl, br; int dl = 0, dr = 0;
+        const int32_t rl = build_small(begin, mid, nodeIdx + 1, depth + 1, bl, dl);
+        const int32_t rr = build_small(mid, end, nodeIdx + (int32_t)bestPos, depth + 1, br, dr);
+        write_node(nodeIdx, bl, br, rl, rr);
+        outBox = bl; grow(outBox, br);
+        outDepth = std::max(dl, dr);
+        return nodeIdx;
+    }
+
+    // builds the subtree over order[begin,end) whose centroids lie in `cbounds`; returns its ref
+    // (>= 0 inner index, < 0 ~leafPosition)
+    int32_t build(uint32_t begin, uint32_t end, int32_t nodeIdx, int depth, const Box& cbounds, int threads, Box& outBox, int& outDepth) {
+        const uint32_t n = end - begin;
+        if (n == 1) { outBox = items[begin].box(); outDepth = depth; return ~(int32_t)begin; }
+        if (n <= kSweepNode) return build_small(begin, end, nodeIdx, depth, outBox, outDepth);
+        Split sp; bool any = false;
+        for (int a = 0; a < 3; ++a) {
+            const float ext = cbounds.hi[a] - cbounds.lo[a];
+            sp.valid[a] = ext > 0.0f && std::isfinite(ext);
+            sp.lo[a] = cbounds.lo[a]; sp.scale[a] = sp.valid[a] ? (float)kBins / ext : 0.0f;
+            any = any || sp.valid[a];
+        }
+        const bool wide = threads > 1 && n >= kParallelNode;
+        Bins bins; bins.clear();
+        if (any) {
+            if (wide) {
+                std::vector<Bins> local((size_t)threads);
+                parallel_chunks(begin, end, threads, [&](int t, uint32_t b, uint32_t e) { local[(size_t)t].clear(); bin_range(b, e, sp, local[(size_t)t]); });
+                for (const Bins& l : local) bins.merge(l);
+            } else {
+                bin_range(begin, end, sp, bins);
+            }
+        }
+        int bestAxis = -1, bestBin = -1; double bestCost = INFINITY;
+        for (int a = 0; a < 3; ++a) {
+            if (!sp.valid[a]) continue;
+            double rightArea[kBins]; uint32_t rightCnt[kBins];
+            Box acc = empty_box(); uint32_t c = 0;
+            for (int k = kBins - 1; k > 0; --k) { grow(acc, bins.box(a, k)); c += bins.cnt[a][k]; rightArea[k] = half_area(acc); rightCnt[k] = c; }
+            acc = empty_box(); c = 0;
+            for (int k = 0; k < kBins - 1; ++k) {
+                grow(acc, bins.box(a, k)); c += bins.cnt[a][k];
+                if (c == 0 || rightCnt[k + 1] == 0) continue;
+                const double cost = half_area(acc) * c + rightArea[k + 1] * rightCnt[k + 1];
+                if (cost < bestCost) { bestCost = cost; bestAxis = a; bestBin = k; }
+            }
+        }
+        uint32_t mid;
+        Box cl = empty_box(), cr = empty_box();
+        if (bestAxis >= 0) {
+            const int a = bestAxis;
+            const float lo = sp.lo[a], scale = sp.scale[a];
+            auto left = [&](const Item& it) { return bin_of(0.5f * it.lo[a] + 0.5f * it.hi[a], lo, scale) <= bestBin; };
+            if (wide) {
+                // stable two-sided scatter through the scratch array: per-chunk counts give every chunk its
+                // own output windows on both sides, so the chunks write without meeting
+                std::vector<uint32_t> nl((size_t)threads, 0), chunkBegin((size_t)threads, end), chunkEnd((size_t)threads, end);
+                parallel_chunks(begin, end, threads, [&](int t, uint32_t b, uint32_t e) {
+                    uint32_t c = 0; for (uint32_t i = b; i < e; ++i) c += left(items[i]) ? 1u : 0u;
+                    nl[(size_t)t] = c; chunkBegin[(size_t)t] = b; chunkEnd[(size_t)t] = e;
+                });
+                uint32_t totalLeft = 0; for (uint32_t c : nl) totalLeft += c;
+                std::vector<uint32_t> offL((size_t)threads), offR((size_t)threads);
+                uint32_t accL = begin, accR = begin + totalLeft;
+                for (int t = 0; t < threads; ++t) {
+                    offL[(size_t)t] = accL; offR[(size_t)t] = accR;
+                    accL += nl[(size_t)t]; accR += (chunkEnd[(size_t)t] - chunkBegin[(size_t)t]) - nl[(size_t)t];
+                }
+                std::vector<Box> lcl((size_t)threads, empty_box()), lcr((size_t)threads, empty_box());
+                parallel_chunks(begin, end, threads, [&](int t, uint32_t b, uint32_t e) {
+                    uint32_t l = offL[(size_t)t], r = offR[(size_t)t];
+                    Box ml = empty_box(), mr = empty_box();
+                    for (uint32_t i = b; i < e; ++i) {
+                        if (left(items[i])) { grow_centroid(ml, items[i]); scratch[l++] = items[i]; }
+                        else { grow_centroid(mr, items[i]); scratch[r++] = items[i]; }
+                    }
+                    lcl[(size_t)t] = ml; lcr[(size_t)t] = mr;
+                });
+                for (int t = 0; t < threads; ++t) { grow(cl, lcl[(size_t)t]); grow(cr, lcr[(size_t)t]); }
+                parallel_chunks(begin, end, threads, [&](int, uint32_t b, uint32_t e) { memcpy(items + b, scratch + b, (size_t)(e - b) * sizeof(Item)); });
+                mid = begin + totalLeft;
+            } else {
+                // two-pointer partition that also collects both sides' centroid bounds (the children need them)
+                uint32_t i = begin, j = end;
+                for (;;) {
+                    while (i < j && left(items[i])) { grow_centroid(cl, items[i]); ++i; }
+                    while (i < j && !left(items[j - 1])) { grow_centroid(cr, items[j - 1]); --j; }
+                    if (i >= j) break;
+                    std::swap(items[i], items[j - 1]);
+                    grow_centroid(cl, items[i]); grow_centroid(cr, items[j - 1]);
+                    ++i; --j;
+                }
+                mid = i;
+            }
+        } else {
+            mid = begin;          // all centroids coincide (or are not finite): split by count
+        }
+        if (mid == begin || mid == end) {
+            mid = begin + n / 2;
+            cl = empty_box(); cr = empty_box();
+            for (uint32_t i = begin; i < end; ++i) {
+                grow_centroid(i < mid ? cl : cr, items[i]);
+            }
+        }
+        const uint32_t nl = mid - begin;
+        const int32_t leftIdx = nodeIdx + 1, rightIdx = nodeIdx + (int32_t)nl;   // left subtree has nl-1 inner nodes
+        Box bl, br; int dl = 0, dr = 0; int32_t rl, rr;
+        if (threads > 1 && n > 8192) {
+            // threads are shared out by size, so that both sides finish together
+            int tl = (int)((double)threads * nl / n + 0.5);
+            tl = tl < 1 ? 1 : (tl > threads - 1 ? threads - 1 : tl);
+            std::thread t([&]() { rl = build(begin, mid, leftIdx, depth + 1, cl, tl, bl, dl); });
+            rr = build(mid, end, rightIdx, depth + 1, cr, threads - tl, br, dr);
+            t.join();
+        } else {
+            rl = build(begin, mid, leftIdx, depth + 1, cl, 1, bl, dl);
+            rr = build(mid, end, rightIdx, depth + 1, cr, 1, br, dr);
+        }
+        write_node(nodeIdx, bl, br, rl, rr);
         outBox = bl; grow(outBox, br);
         outDepth = std::max(dl, dr);
         return nodeIdx;
@@ -123,11 +284,19 @@ struct SahBuilder {
 // order[] in: any permutation of 0..n-1; out: leaf order of the new tree.
 // Returns the root ref; nodes must hold n-1 records.
 inline int32_t build_sah(const Box* prim, uint32_t n, uint32_t* order, Node* nodes, int nthreads, int& maxDepth) {
-    int par = 0;
-    while ((1 << par) < nthreads) ++par;
-    SahBuilder b{prim, order, nodes, par};
+    std::vector<Item> items(n), scratch(n);
+    // the root's centroid bounds: the only pass of this kind
+    Box cb = empty_box();
+    for (uint32_t i = 0; i < n; ++i) {
+        const Box& pb = prim[order[i]];
+        for (int a = 0; a < 3; ++a) { items[i].lo[a] = pb.lo[a]; items[i].hi[a] = pb.hi[a]; }
+        items[i].id = order[i]; items[i].pad = 0;
+        SahBuilder::grow_centroid(cb, items[i]);
+    }
+    SahBuilder b{items.data(), nodes, scratch.data()};
     Box root; int depth = 0;
-    int32_t ref = b.build(0, n, 0, 0, root, depth);
+    const int32_t ref = b.build(0, n, 0, 0, cb, nthreads < 1 ? 1 : nthreads, root, depth);
+    for (uint32_t i = 0; i < n; ++i) order[i] = items[i].id;
     maxDepth = depth;
     return ref;
 }
@@ -174,17 +343,30 @@ struct Collapser {
         return best;
     }
 
-    // children point at higher indices than their parent (build_sah numbers nodes in pre-order)
-    void solve(size_t numNodes) {
-        T.assign(4 * numNodes, 0.0f);
-        for (size_t n = numNodes; n-- > 0;) {
-            Child c[2]; children_of(bvh2[n], c);
-            Box u = c[0].box; grow(u, c[1].box);
-            int k;
-            const float s2 = split(c, 2, k), s3 = split(c, 3, k), s4 = split(c, 4, k);
-            const float keep = (float)half_area(u) + s4;
-            T[4 * n + 0] = keep; T[4 * n + 1] = std::min(keep, s2); T[4 * n + 2] = std::min(keep, s3); T[4 * n + 3] = std::min(keep, s4);
+    void solve_node(size_t n) {
+        Child c[2]; children_of(bvh2[n], c);
+        Box u = c[0].box; grow(u, c[1].box);
+        int k;
+        const float s2 = split(c, 2, k), s3 = split(c, 3, k), s4 = split(c, 4, k);
+        const float keep = (float)half_area(u) + s4;
+        T[4 * n + 0] = keep; T[4 * n + 1] = std::min(keep, s2); T[4 * n + 2] = std::min(keep, s3); T[4 * n + 3] = std::min(keep, s4);
+    }
+    // build_sah numbers nodes in pre-order: the subtree of node n is the index range [n, end), its left
+    // subtree starts at n + 1 and its right subtree where the right child's index says. Bottom-up = by
+    // descending index; disjoint subtrees are solved on separate threads.
+    void solve(size_t n, size_t end, int threads) {
+        Child c[2]; children_of(bvh2[n], c);
+        if (threads > 1 && end - n > 65536 && c[0].ref >= 0 && c[1].ref >= 0) {
+            const size_t l = (size_t)c[0].ref, r = (size_t)c[1].ref;
+            int tl = (int)((double)threads * (double)(r - l) / (double)(end - n) + 0.5);
+            tl = tl < 1 ? 1 : (tl > threads - 1 ? threads - 1 : tl);
+            std::thread t([&]() { solve(l, r, tl); });
+            solve(r, end, threads - tl);
+            t.join();
+            solve_node(n);
+            return;
         }
+        for (size_t i = end; i-- > n;) solve_node(i);
     }
 
     // the children that subtree `ref` contributes when it may use up to j slots
@@ -226,9 +408,10 @@ struct Collapser {
 };
 
 // Folds the binary tree of `numNodes` inner nodes rooted at node `root2` into 4-wide nodes (root = index 0).
-inline void collapse4(const Node* bvh2, size_t numNodes, int32_t root2, std::vector<Node4>& out, int& maxDepth) {
+inline void collapse4(const Node* bvh2, size_t numNodes, int32_t root2, std::vector<Node4>& out, int& maxDepth, int nthreads = 1) {
     Collapser c{bvh2, out};
-    c.solve(numNodes);
+    c.T.assign(4 * numNodes, 0.0f);
+    c.solve((size_t)root2, numNodes, nthreads < 1 ? 1 : nthreads);
     c.emit(root2, 0);
     maxDepth = c.maxDepth;
 }

@@ -57,7 +57,7 @@ static void run(uint32_t n, unsigned seed, int threads, bool degenerate) {
     std::vector<uint32_t> sorted = order; std::sort(sorted.begin(), sorted.end());
     for (uint32_t i = 0; i < n; ++i) CHECK(sorted[i] == i);                       // still a permutation
     std::vector<Node4> wide; int depth4 = 0;
-    collapse4(bin.data(), bin.size(), root, wide, depth4);
+    collapse4(bin.data(), bin.size(), root, wide, depth4, threads);
     CHECK(wide.size() <= bin.size());
     Walker w{wide, prim, order, std::vector<int>(n, 0)};
     w.walk(0, 0);
