@@ -14,6 +14,10 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <atomic>
+#include <mutex>
+#include <thread>
+#include <chrono>
 #include <vector>
 
 static thread_local std::string g_err;
@@ -138,15 +142,54 @@ void emit_leaf(const RtxObject& o, int32_t objectID, int32_t boxID, float4* leaf
 
 const int32_t kNoChild = (int32_t)0x80000000;   // never passes (see traverse_bvh)
 
-int flatten(const RtxSceneDesc& s, bool useBVH, bool wantFast, int nthreads, Flat& f) {
-    const uint64_t nObj = s.numObjects, nBox = s.numBoxes;
-    for (uint64_t i = 0; i < nObj; ++i) {
-        const int32_t m = s.objects[i].materialID;
-        if (m < 0 || (uint64_t)m >= s.numMaterials) return fail("object " + std::to_string(i) + ": materialID out of range");
+struct PhaseClock {
+    const bool on = getenv("RTX_VERBOSE") != nullptr;
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    void lap(const char* what) {
+        if (!on) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[rtx]   %-28s %.3f s\n", what, std::chrono::duration<double>(now - t).count());
+        t = now;
     }
+};
+
+// f(begin, end) over [0, n) on up to `threads` host threads
+template <class F>
+void parallel_for(uint64_t n, int threads, F&& f) {
+    if (threads <= 1 || n < 65536) { f((uint64_t)0, n); return; }
+    const uint64_t per = (n + (uint64_t)threads - 1) / (uint64_t)threads;
+    std::vector<std::thread> pool;
+    for (int t = 1; t < threads; ++t) {
+        const uint64_t b = std::min(n, (uint64_t)t * per), e = std::min(n, b + per);
+        if (b < e) pool.emplace_back([&f, b, e]() { f(b, e); });
+    }
+    f((uint64_t)0, std::min(n, per));
+    for (auto& th : pool) th.join();
+}
+
+// first error reported by any worker
+struct ErrorSlot {
+    std::mutex m; std::string msg;
+    void set(const std::string& s) { std::lock_guard<std::mutex> g(m); if (msg.empty()) msg = s; }
+    bool any() { std::lock_guard<std::mutex> g(m); return !msg.empty(); }
+};
+
+int flatten(const RtxSceneDesc& s, bool useBVH, bool wantFast, int nthreads, Flat& f) {
+    PhaseClock clock;
+    const uint64_t nObj = s.numObjects, nBox = s.numBoxes;
+    ErrorSlot err;
+    parallel_for(nObj, nthreads, [&](uint64_t b, uint64_t e) {
+        for (uint64_t i = b; i < e; ++i) {
+            const int32_t m = s.objects[i].materialID;
+            if (m < 0 || (uint64_t)m >= s.numMaterials) { err.set("object " + std::to_string(i) + ": materialID out of range"); return; }
+        }
+    });
+    if (err.any()) return fail(err.msg);
     if (!useBVH) {
         f.leaf.resize(nObj * 4); f.shade.resize(nObj * 3);
-        for (uint64_t i = 0; i < nObj; ++i) emit_leaf(s.objects[i], (int32_t)i, (int32_t)i, &f.leaf[i * 4], &f.shade[i * 3]);
+        parallel_for(nObj, nthreads, [&](uint64_t b, uint64_t e) {
+            for (uint64_t i = b; i < e; ++i) emit_leaf(s.objects[i], (int32_t)i, (int32_t)i, &f.leaf[i * 4], &f.shade[i * 3]);
+        });
         f.rootRef = 0; f.maxDepth = 0;
         return 0;
     }
@@ -160,62 +203,107 @@ int flatten(const RtxSceneDesc& s, bool useBVH, bool wantFast, int nthreads, Fla
         if (box.objectID != -1) {
             if (box.objectID < 0 || (uint64_t)box.objectID >= nObj) return fail("box " + std::to_string(b) + ": objectID out of range");
             slotOf[b] = nLeaf++;
-            leafBox.push_back((int32_t)b);
         } else {
             slotOf[b] = nInner++;
         }
     }
-    // depth + tree check (every box reached at most once) + nesting check (parent contains child)
+    leafBox.resize((size_t)nLeaf);
+    parallel_for(nBox, nthreads, [&](uint64_t b0, uint64_t b1) {
+        for (uint64_t b = b0; b < b1; ++b) if (s.boxes[b].objectID != -1) leafBox[(size_t)slotOf[b]] = (int32_t)b;
+    });
+    // depth + tree check (every box reached at most once) + nesting check (parent contains child) + well-formed
+    // boxes. The walk starts breadth-first on one thread; once the frontier is wide enough its subtrees are
+    // walked depth-first on all threads (a box reached twice — by any two walkers — is an error).
     {
         std::vector<uint8_t> seen(nBox, 0);
-        std::vector<std::pair<int32_t, int32_t>> st;
-        st.emplace_back(0, 0);
-        int maxDepth = 0;
-        while (!st.empty()) {
-            auto [b, depth] = st.back(); st.pop_back();
-            if (seen[b]) return fail("boxes do not form a tree (box " + std::to_string(b) + " reached twice)");
-            seen[b] = 1;
-            maxDepth = std::max(maxDepth, depth);
+        std::atomic<int> maxDepthAll{0};
+        std::atomic<bool> nestedAll{true};
+        auto visit = [&](int32_t b, int depth, std::vector<std::pair<int32_t, int32_t>>& out) -> bool {
+            if (__atomic_exchange_n(&seen[(size_t)b], (uint8_t)1, __ATOMIC_RELAXED)) {
+                err.set("boxes do not form a tree (box " + std::to_string(b) + " reached twice)");
+                return false;
+            }
             const RtxBoundingBox& box = s.boxes[b];
             // the fast path picks a box's near and far planes by the sign of the ray direction, which
             // equals the reference's min/max of the two plane distances only when min <= max (NaN fails too)
             if (b != 0 && !(box.minimalPosition.x <= box.maximalPosition.x && box.minimalPosition.y <= box.maximalPosition.y &&
-                            box.minimalPosition.z <= box.maximalPosition.z)) f.nested = false;
-            if (box.objectID != -1) continue;
+                            box.minimalPosition.z <= box.maximalPosition.z)) nestedAll = false;
+            if (box.objectID != -1) return true;
             const int32_t child[2] = {box.leftID, box.rightID};
             for (int k = 0; k < 2; ++k) {
                 if (child[k] == -1) continue;   // the reference guards children with != -1 (src/ThreadedShader.cpp:380,387)
-                if (child[k] < 0 || (uint64_t)child[k] >= nBox) return fail("box " + std::to_string(b) + ": child out of range");
+                if (child[k] < 0 || (uint64_t)child[k] >= nBox) { err.set("box " + std::to_string(b) + ": child out of range"); return false; }
                 const RtxBoundingBox& c = s.boxes[child[k]];
                 const bool in = box.minimalPosition.x <= c.minimalPosition.x && box.minimalPosition.y <= c.minimalPosition.y &&
                                 box.minimalPosition.z <= c.minimalPosition.z && box.maximalPosition.x >= c.maximalPosition.x &&
                                 box.maximalPosition.y >= c.maximalPosition.y && box.maximalPosition.z >= c.maximalPosition.z;
-                if (!in && b != 0) f.nested = false;     // the root's own box is never tested by the reference
-                st.emplace_back(child[k], depth + 1);
+                if (!in && b != 0) nestedAll = false;     // the root's own box is never tested by the reference
+                out.emplace_back(child[k], depth + 1);
             }
+            return true;
+        };
+        auto walk = [&](std::vector<std::pair<int32_t, int32_t>>& st) {
+            int deepest = 0;
+            while (!st.empty()) {
+                auto [b, depth] = st.back(); st.pop_back();
+                deepest = std::max(deepest, depth);
+                if (!visit(b, depth, st)) return;
+            }
+            int cur = maxDepthAll.load();
+            while (deepest > cur && !maxDepthAll.compare_exchange_weak(cur, deepest)) {}
+        };
+        std::vector<std::pair<int32_t, int32_t>> frontier{{0, 0}}, next;
+        int topDepth = 0;
+        while (!frontier.empty() && frontier.size() < (size_t)(8 * std::max(1, nthreads)) && !err.any()) {
+            next.clear();
+            for (auto [b, depth] : frontier) { topDepth = std::max(topDepth, depth); if (!visit(b, depth, next)) break; }
+            frontier.swap(next);
         }
-        f.maxDepth = maxDepth;
-        for (uint64_t b = 0; b < nBox; ++b) if (!seen[b] && s.boxes[b].objectID != -1) f.nested = false;   // unreachable leaf: keep the reference topology
+        maxDepthAll = topDepth;
+        if (!err.any() && !frontier.empty()) {
+            std::atomic<size_t> nextRoot{0};
+            std::vector<std::thread> pool;
+            auto worker = [&]() {
+                std::vector<std::pair<int32_t, int32_t>> st;
+                for (size_t i = nextRoot++; i < frontier.size() && !err.any(); i = nextRoot++) { st.assign(1, frontier[i]); walk(st); }
+            };
+            for (int t = 1; t < nthreads; ++t) pool.emplace_back(worker);
+            worker();
+            for (auto& th : pool) th.join();
+        }
+        if (err.any()) return fail(err.msg);
+        f.maxDepth = maxDepthAll;
+        f.nested = nestedAll;
+        std::atomic<bool> unreachable{false};
+        parallel_for(nBox, nthreads, [&](uint64_t b0, uint64_t b1) {
+            for (uint64_t b = b0; b < b1; ++b) if (!seen[b] && s.boxes[b].objectID != -1) { unreachable = true; return; }
+        });
+        if (unreachable) f.nested = false;   // unreachable leaf: keep the reference topology
     }
+    clock.lap("validate + walk boxes");
     // own tree over the same leaf boxes (DESIGN.md "Topology freedom")
     std::vector<uint32_t> order((size_t)nLeaf);
     for (int32_t k = 0; k < nLeaf; ++k) order[k] = (uint32_t)k;
     if (wantFast && f.nested && nLeaf >= 2) {
         std::vector<rtxbuild::Box> prim((size_t)nLeaf);
-        for (int32_t k = 0; k < nLeaf; ++k) {
-            const RtxBoundingBox& b = s.boxes[leafBox[k]];
-            prim[k].lo[0] = b.minimalPosition.x; prim[k].lo[1] = b.minimalPosition.y; prim[k].lo[2] = b.minimalPosition.z;
-            prim[k].hi[0] = b.maximalPosition.x; prim[k].hi[1] = b.maximalPosition.y; prim[k].hi[2] = b.maximalPosition.z;
-        }
+        parallel_for((uint64_t)nLeaf, nthreads, [&](uint64_t k0, uint64_t k1) {
+            for (uint64_t k = k0; k < k1; ++k) {
+                const RtxBoundingBox& b = s.boxes[leafBox[k]];
+                prim[k].lo[0] = b.minimalPosition.x; prim[k].lo[1] = b.minimalPosition.y; prim[k].lo[2] = b.minimalPosition.z;
+                prim[k].hi[0] = b.maximalPosition.x; prim[k].hi[1] = b.maximalPosition.y; prim[k].hi[2] = b.maximalPosition.z;
+            }
+        });
         std::vector<rtxbuild::Node> bin((size_t)nLeaf - 1);
         int binDepth = 0;
         const int32_t binRoot = rtxbuild::build_sah(prim.data(), (uint32_t)nLeaf, order.data(), bin.data(), nthreads, binDepth);
+        clock.lap("binned-SAH build");
         if (binDepth > 60) {
             for (int32_t k = 0; k < nLeaf; ++k) order[k] = (uint32_t)k;      // degenerate input: keep the reference topology
         } else {
             f.fast.reserve((size_t)nLeaf / 2);
             rtxbuild::collapse4(bin.data(), bin.size(), binRoot, f.fast, f.fastDepth, nthreads);
             f.fastRoot = 0;
+            clock.lap("fold into 4-wide nodes");
         }
     } else if (wantFast && f.nested && nLeaf <= 1) {
         rtxbuild::Box b;
@@ -229,15 +317,18 @@ int flatten(const RtxSceneDesc& s, bool useBVH, bool wantFast, int nthreads, Fla
     }
     // leaves in the new order; reference leaf index -> position
     std::vector<int32_t> posOf((size_t)nLeaf);
-    for (int32_t p = 0; p < nLeaf; ++p) posOf[order[p]] = p;
     f.leaf.resize((size_t)nLeaf * 4); f.shade.resize((size_t)nLeaf * 3);
-    for (int32_t p = 0; p < nLeaf; ++p) {
-        const int32_t b = leafBox[order[p]];
-        emit_leaf(s.objects[s.boxes[b].objectID], s.boxes[b].objectID, b, &f.leaf[(size_t)p * 4], &f.shade[(size_t)p * 3]);
-    }
+    parallel_for((uint64_t)nLeaf, nthreads, [&](uint64_t p0, uint64_t p1) {
+        for (uint64_t p = p0; p < p1; ++p) {
+            posOf[order[p]] = (int32_t)p;
+            const int32_t b = leafBox[order[p]];
+            emit_leaf(s.objects[s.boxes[b].objectID], s.boxes[b].objectID, b, &f.leaf[(size_t)p * 4], &f.shade[(size_t)p * 3]);
+        }
+    });
     // the reference's own topology (used by RTX_TRAVERSE_EXACT and by lanes that cannot use the own tree)
-    f.inner.assign((size_t)nInner * 4, make_float4(0, 0, 0, 0));
-    for (uint64_t b = 0; b < nBox; ++b) {
+    f.inner.resize((size_t)nInner * 4);
+    parallel_for(nBox, nthreads, [&](uint64_t b0, uint64_t b1) {
+      for (uint64_t b = b0; b < b1; ++b) {
         const RtxBoundingBox& box = s.boxes[b];
         if (box.objectID != -1) continue;
         float lo[2][3] = {{0, 0, 0}, {0, 0, 0}}, hi[2][3] = {{0, 0, 0}, {0, 0, 0}};
@@ -255,8 +346,10 @@ int flatten(const RtxSceneDesc& s, bool useBVH, bool wantFast, int nthreads, Fla
         n[1] = make_float4(hi[0][1], hi[0][2], lo[1][0], lo[1][1]);
         n[2] = make_float4(lo[1][2], hi[1][0], hi[1][1], hi[1][2]);
         n[3] = make_float4(i2f(ref[0]), i2f(ref[1]), 0, 0);
-    }
+      }
+    });
     f.rootRef = s.boxes[0].objectID != -1 ? ~posOf[slotOf[0]] : slotOf[0];
+    clock.lap("leaf / shade / inner records");
     return 0;
 }
 
@@ -468,6 +561,7 @@ int rtx_create(const RtxSceneDesc* scene, const RtxConfig* cfgIn, RtxRenderer** 
 
     Flat flat;
     const bool wantFast = cfg.traversal != RTX_TRAVERSE_EXACT;
+    PhaseClock createClock;
     if (flatten(*scene, useBVH, wantFast, 16, flat)) return 1;
     if (useBVH && flat.maxDepth > 62) return fail("BVH deeper than 62 levels is not supported (the reference's own stack holds 32)");
 
@@ -590,6 +684,7 @@ int rtx_create(const RtxSceneDesc* scene, const RtxConfig* cfgIn, RtxRenderer** 
     for (int b = 0; b < 4; ++b) r->queueHint[b] = r->numSlots;
     set_grids(r, r->numSlots);
     CREATE_HIP(hipDeviceSynchronize());
+    createClock.lap("rtx_create total");
     if (getenv("RTX_VERBOSE"))
         fprintf(stderr, "[rtx] %d leaves, reference tree depth %d, own tree %s depth %d, stack %d entries, LDS %zu B/block, %d blocks/CU x %d CUs, mode %d\n",
                 r->sc.numLeaves, flat.maxDepth, flat.fast.empty() ? "absent" : "built", flat.fastDepth, r->sc.stackDepth, r->ldsTrace,
