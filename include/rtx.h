@@ -136,7 +136,9 @@ typedef struct RtxConfig {
     int32_t countStats;    /* 1: count node/leaf visits per frame (slower kernels)   */
     int32_t framesInFlight;/* frames that may overlap on the device when rtx_render is called with
                               pixels_rgba == NULL (each has its own stream and path state; the running
-                              mean is still updated in frame order); 0 -> 3, 1 = strictly serial */
+                              mean is still updated in frame order); 1 = strictly serial; 0 -> as many as the
+                              process has hardware queues for: 3 with HIP's default GPU_MAX_HW_QUEUES=4,
+                              6 with GPU_MAX_HW_QUEUES=8 (an environment variable HIP reads at start-up) */
 } RtxConfig;
 
 typedef struct RtxCounters {

@@ -29,8 +29,8 @@ static int fail(const std::string& m) { g_err = m; return 1; }
         if (e_ != hipSuccess) return fail(std::string(#expr) + ": " + hipGetErrorString(e_)); \
     } while (0)
 
-static const int kRing = 8;       // frames whose timing events are kept; a frame's timing is read kLag frames later
-static const int kLag = 4;
+static const int kRing = 16;      // frames whose timing events are kept; a frame's timing is read kLag frames later
+static const int kLag = 8;
 static const int kEvents = 10;    // start + one per kernel (8) + end
 
 struct RtxRenderer {
@@ -656,7 +656,12 @@ int rtx_create(const RtxSceneDesc* scene, const RtxConfig* cfgIn, RtxRenderer** 
     if (r->ldsTrace) blocksPerCU = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / r->ldsTrace));
     r->gridTrace = r->numCUs * blocksPerCU;
     if (culled) r->ldsSlow = (size_t)std::max(2, flat.maxDepth + 2) * RTX_BLOCK * sizeof(int);
-    int depth = cfg.framesInFlight > 0 ? cfg.framesInFlight : 3;
+    // Streams beyond the hardware queues of the process share a queue and serialise (measured: 4 frames on the
+    // default 4 queues are slower than 3), so the default depth follows GPU_MAX_HW_QUEUES, which HIP reads when
+    // the process initialises it: 3 frames on 4 queues, 6 on 8.
+    int hwQueues = 4;
+    if (const char* e = getenv("GPU_MAX_HW_QUEUES")) hwQueues = std::max(1, atoi(e));
+    int depth = cfg.framesInFlight > 0 ? cfg.framesInFlight : (hwQueues <= 4 ? std::max(1, hwQueues - 1) : std::min(hwQueues - 2, 8));
     if (const char* e = getenv("RTX_FRAMES_IN_FLIGHT")) depth = atoi(e);
     depth = std::max(1, std::min(depth, kLag));
     r->ctx.resize((size_t)depth);
@@ -689,8 +694,8 @@ int rtx_create(const RtxSceneDesc* scene, const RtxConfig* cfgIn, RtxRenderer** 
         fprintf(stderr, "[rtx] %d leaves, reference tree depth %d, own tree %s depth %d, stack %d entries, LDS %zu B/block, %d blocks/CU x %d CUs, mode %d\n",
                 r->sc.numLeaves, flat.maxDepth, flat.fast.empty() ? "absent" : "built", flat.fastDepth, r->sc.stackDepth, r->ldsTrace,
                 blocksPerCU, r->numCUs, r->mode),
-        fprintf(stderr, "[rtx] shade grid %d blocks (%d per CU), queue capacity %zu entries for %zu slots, %zu wide nodes (%.2f per leaf)\n",
-                r->gridShade, shadeBlocksPerCU, nq, n, flat.fast.size(), r->sc.numLeaves ? (double)flat.fast.size() / r->sc.numLeaves : 0.0);
+        fprintf(stderr, "[rtx] %d frames in flight (%d hardware queues), shade grid %d blocks (%d per CU), queue capacity %zu entries for %zu slots, %zu wide nodes (%.2f per leaf)\n",
+                depth, hwQueues, r->gridShade, shadeBlocksPerCU, nq, n, flat.fast.size(), r->sc.numLeaves ? (double)flat.fast.size() / r->sc.numLeaves : 0.0);
     *out = r;
     return 0;
 }

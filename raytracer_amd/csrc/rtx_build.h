@@ -55,9 +55,15 @@ struct SahBuilder {
     Node* nodes;            // n-1 inner records
     Item* scratch;          // n entries, for the parallel partition
 
-    static const int kBins = 16;
+#ifndef RTX_SAH_BINS
+#define RTX_SAH_BINS 16
+#endif
+#ifndef RTX_SAH_SWEEP
+#define RTX_SAH_SWEEP 16
+#endif
+    static const int kBins = RTX_SAH_BINS;
     static const uint32_t kParallelNode = 1u << 17;
-    static const uint32_t kSweepNode = 16;
+    static const uint32_t kSweepNode = RTX_SAH_SWEEP;
 
     // a bin's box as two 4-float rows (lo.xyz _, hi.xyz _), the layout of an Item, so that growing it by an
     // item is two packed min/max; the 4th lanes carry the item's id / padding bits and are never read
