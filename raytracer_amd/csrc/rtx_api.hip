@@ -135,9 +135,14 @@ void emit_leaf(const RtxObject& o, int32_t objectID, int32_t boxID, float4* leaf
         leaf[3] = make_float4(0, 0, 0, 0);
     }
     const RtxVec4 n0 = o.normals[0], n1 = o.normals[1], n2 = o.normals[2];
-    shade[0] = make_float4(n0.x, n0.y, n0.z, n1.x);
-    shade[1] = make_float4(n1.y, n1.z, n2.x, n2.y);
-    shade[2] = make_float4(n2.z, i2f(o.materialID), 0, 0);
+    // the shading record is one 128-byte line of its own: a copy of the leaf record (hit_normal needs the
+    // vertices) followed by the normals and the material, so that k_shade touches ONE scattered line per hit
+    // instead of a leaf line plus a 48-byte record that straddles lines a third of the time
+    for (int k = 0; k < 4; ++k) shade[k] = leaf[k];
+    shade[4] = make_float4(n0.x, n0.y, n0.z, n1.x);
+    shade[5] = make_float4(n1.y, n1.z, n2.x, n2.y);
+    shade[6] = make_float4(n2.z, i2f(o.materialID), 0, 0);
+    shade[7] = make_float4(0, 0, 0, 0);
 }
 
 const int32_t kNoChild = (int32_t)0x80000000;   // never passes (see traverse_bvh)
@@ -186,9 +191,9 @@ int flatten(const RtxSceneDesc& s, bool useBVH, bool wantFast, int nthreads, Fla
     });
     if (err.any()) return fail(err.msg);
     if (!useBVH) {
-        f.leaf.resize(nObj * 4); f.shade.resize(nObj * 3);
+        f.leaf.resize(nObj * 4); f.shade.resize(nObj * 8);
         parallel_for(nObj, nthreads, [&](uint64_t b, uint64_t e) {
-            for (uint64_t i = b; i < e; ++i) emit_leaf(s.objects[i], (int32_t)i, (int32_t)i, &f.leaf[i * 4], &f.shade[i * 3]);
+            for (uint64_t i = b; i < e; ++i) emit_leaf(s.objects[i], (int32_t)i, (int32_t)i, &f.leaf[i * 4], &f.shade[i * 8]);
         });
         f.rootRef = 0; f.maxDepth = 0;
         return 0;
@@ -317,12 +322,12 @@ int flatten(const RtxSceneDesc& s, bool useBVH, bool wantFast, int nthreads, Fla
     }
     // leaves in the new order; reference leaf index -> position
     std::vector<int32_t> posOf((size_t)nLeaf);
-    f.leaf.resize((size_t)nLeaf * 4); f.shade.resize((size_t)nLeaf * 3);
+    f.leaf.resize((size_t)nLeaf * 4); f.shade.resize((size_t)nLeaf * 8);
     parallel_for((uint64_t)nLeaf, nthreads, [&](uint64_t p0, uint64_t p1) {
         for (uint64_t p = p0; p < p1; ++p) {
             posOf[order[p]] = (int32_t)p;
             const int32_t b = leafBox[order[p]];
-            emit_leaf(s.objects[s.boxes[b].objectID], s.boxes[b].objectID, b, &f.leaf[(size_t)p * 4], &f.shade[(size_t)p * 3]);
+            emit_leaf(s.objects[s.boxes[b].objectID], s.boxes[b].objectID, b, &f.leaf[(size_t)p * 4], &f.shade[(size_t)p * 8]);
         }
     });
     // the reference's own topology (used by RTX_TRAVERSE_EXACT and by lanes that cannot use the own tree)

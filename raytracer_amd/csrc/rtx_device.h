@@ -8,7 +8,8 @@
 //   leaf[]    64 B / primitive  : q0 = (A.x A.y A.z e1.x) q1 = (e1.y e1.z e2.x e2.y)
 //             q2 = (e2.z objectID boxID type)  q3 = (B.x B.y C.x C.y)   [q3 only read when shading]
 //             sphere: A = centre, e1.x = radius
-//   shade[]   48 B / primitive  : q0 = (n0.x n0.y n0.z n1.x) q1 = (n1.y n1.z n2.x n2.y) q2 = (n2.z materialID - -)
+//   shade[]  128 B / primitive  : q0..q3 = copy of the leaf record, q4 = (n0.x n0.y n0.z n1.x) q5 = (n1.y n1.z n2.x n2.y)
+//                                 q6 = (n2.z materialID - -) q7 unused: one line per shaded hit
 //   materials 128 B each, reference layout (src/Material.h:7-25)
 // One inner visit = one 64-byte line (the reference touches three: the node and
 // both children, src/ThreadedShader.cpp:355,381,388); one leaf test = one line

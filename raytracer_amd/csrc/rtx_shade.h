@@ -156,10 +156,9 @@ struct HitPrim {
 };
 
 __device__ __forceinline__ HitPrim load_prim(const DevScene& sc, int leafIdx) {
-    const float4* L = sc.leaf + (size_t)leafIdx * 4;
-    const float4* S = sc.shade + (size_t)leafIdx * 3;
-    float4 q0 = L[0], q1 = L[1], q2 = L[2], q3 = L[3];
-    float4 s0 = S[0], s1 = S[1], s2 = S[2];
+    const float4* S = sc.shade + (size_t)leafIdx * 8;       // one 128-byte line: leaf record copy + normals + material
+    float4 q0 = S[0], q1 = S[1], q2 = S[2], q3 = S[3];
+    float4 s0 = S[4], s1 = S[5], s2 = S[6];
     HitPrim p;
     p.type = __float_as_int(q2.w);
     p.A = mk4(q0.x, q0.y, q0.z); p.e1 = mk4(q0.w, q1.x, q1.y); p.e2 = mk4(q1.z, q1.w, q2.x);
