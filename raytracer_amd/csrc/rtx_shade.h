@@ -74,19 +74,26 @@ __device__ __forceinline__ float ggx_aniso(F4 h, float ax, float ay) {          
     float temp = (dotHX2 / ax2 + dotHY2 / ay2 + cos2Theta);
     return 1.0f / RTX_PI_F * 1.0f / (ax * ay * temp * temp);
 }
+// The reference writes sqrt(x) with a float x, which C++ resolves to the double overload, and stores the result in
+// a float. Rounding a correctly rounded double square root to float gives the correctly rounded float square
+// root (double rounding is innocuous for sqrt when the wide format has >= 2p + 2 bits: 53 >= 50), so the
+// correctly rounded sqrtf (-fhip-fp32-correctly-rounded-divide-sqrt) returns the same bits without the
+// double-precision sequence. Only where the double result is NOT used further in double arithmetic.
+__device__ __forceinline__ float sqrt_f32_via_f64(float x) { return sqrtf(x); }
+
 __device__ __forceinline__ float smith_g1_bsdf(F4 vec, F4 h, float ax, float ay) {   // :56-72
     float cos2Theta = h.y * h.y;
     float sin2Theta = 1.0f - cos2Theta;
-    float tanTheta = (float)sqrt((double)(sin2Theta / cos2Theta));
+    float tanTheta = sqrt_f32_via_f64(sin2Theta / cos2Theta);
     float cos2Phi = vec.x * vec.x;
     float sin2Phi = 1.0f - cos2Phi;
-    float a = (float)sqrt((double)(cos2Phi * ax * ax + sin2Phi * ay * ay));
+    float a = sqrt_f32_via_f64(cos2Phi * ax * ax + sin2Phi * ay * ay);
     float a2Tan2Theta = a * a * tanTheta * tanTheta;
     float lambda = (float)(0.5 * (-1.0 + sqrt((double)(1.0f + a2Tan2Theta))));
     return 1.0f / (1.0f + lambda);
 }
 __device__ __forceinline__ void ax_ay(const DevMaterial& m, float& ax, float& ay) {  // :76-81
-    float aspect = (float)sqrt((double)(1.0f - 0.9f * m.anisotropy));
+    float aspect = sqrt_f32_via_f64(1.0f - 0.9f * m.anisotropy);
     float roughnessSqr = m.roughness * m.roughness;
     ax = fmaxf(0.001f, roughnessSqr / aspect);
     ay = fmaxf(0.001f, roughnessSqr * aspect);
@@ -120,7 +127,7 @@ __device__ __forceinline__ F4 unpack(uint32_t c) {                              
 __device__ __forceinline__ F4 color_sample(const DevScene& sc, float u, float v, int width, int height, int offsetInt) {
     int offset = (int)(float)offsetInt;
     float tcx = u * (float)(width - 1), tcy = v * (float)(height - 1);
-    float tx = (float)floor((double)tcx), ty = (float)floor((double)tcy);
+    float tx = floorf(tcx), ty = floorf(tcy);      // (float)floor((double)x) == floorf(x) exactly
     float fx = tcx - tx, fy = tcy - ty;
     int itx = to_int(tx), ity = to_int(ty);
     uint32_t i00 = (uint32_t)offset + (uint32_t)(ity * width) + (uint32_t)itx;
@@ -228,7 +235,7 @@ __device__ __forceinline__ F4 compute_color(const DevScene& sc, F4 camPos, F4& r
         if (eta * sinR2 > 1.0f) {
             refractionDirection = mk4(0, 0, 0);
         } else {
-            float cosR2 = (float)sqrt((double)(1.0f - sinR2 * sinR2));
+            float cosR2 = shading::sqrt_f32_via_f64(1.0f - sinR2 * sinR2);
             refractionDirection = normalize4(add4(mul4(viewVector, eta), mul4(normal, (eta * cosI - cosR2))));
         }
     }
