@@ -68,9 +68,18 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP backend has no CPU fallback)")
+    # RTX_BENCH_BACKEND=gloo rehearses the multi-rank path where the ranks cannot each have a GPU (several ranks on
+    # one device, tiles staged through host memory around the collective); the measured configuration is nccl.
+    backend = os.environ.get("RTX_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
+    red_device = "cuda" if backend == "nccl" else "cpu"
 
     from raytracer_amd import _capi
     from raytracer_amd.dist import DeviceGather
@@ -88,7 +97,7 @@ def main():
                        frames_in_flight=args.frames_in_flight)
     t_create = time.time() - t0
     W, H = shader.width, shader.height
-    gather = DeviceGather(shader, rank, world, torch.device("cuda", local_rank)) if world > 1 else None
+    gather = DeviceGather(shader, rank, world, torch.device("cuda", local_rank), host_staging=backend != "nccl") if world > 1 else None
     cam = scene.camera
 
     def step(i):
@@ -125,8 +134,8 @@ def main():
     elapsed = time.perf_counter() - t0
 
     rays_local = float(c.rays)
-    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    rsum = torch.tensor([rays_local], dtype=torch.float64, device="cuda")
+    t = torch.tensor([elapsed], dtype=torch.float64, device=red_device)
+    rsum = torch.tensor([rays_local], dtype=torch.float64, device=red_device)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(rsum, op=dist.ReduceOp.SUM)
@@ -247,7 +256,7 @@ def main():
                "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": args.workload, "triangles": ntri, "resolution": [W, H], "bounces": 4,
                           "spp_per_step": 1, "traversal": args.traversal, "partition": f"tiles64x32 round-robin x{world}",
-                          "camera": "orbit" if args.orbit else "fixed", "frames_in_flight": args.frames_in_flight or 6, "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES")},
+                          "camera": "orbit" if args.orbit else "fixed", "collective": backend if world > 1 else None, "frames_in_flight": args.frames_in_flight or 6, "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES")},
                "roofline": roofline, "cpu_baseline": cpu, "extra": extra}
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -72,21 +72,36 @@ class DeviceGather:
     """GPU variant: packs this rank's tiles with rtx_pack_tiles into a torch CUDA
     tensor, gathers over the process group (backend "nccl" = RCCL), and on rank 0
     scatters every rank's tiles into the resident framebuffer with
-    rtx_unpack_tiles. Buffers are allocated once."""
+    rtx_unpack_tiles. Buffers are allocated once.
 
-    def __init__(self, shader, rank, world_size, device, group=None):
+    host_staging=True moves the packed tiles through host memory around the
+    collective, for process groups that cannot gather device tensors (gloo): the
+    way to rehearse the multi-rank path with several ranks on one GPU."""
+
+    def __init__(self, shader, rank, world_size, device, group=None, host_staging=False):
         import torch
         self.shader, self.rank, self.world, self.group = shader, rank, world_size, group
+        self.host_staging = host_staging
         n = max(shader.packed_floats(r) for r in range(world_size))
         self.send = torch.zeros(n, dtype=torch.float32, device=device)
-        self.recv = [torch.zeros(n, dtype=torch.float32, device=device) for _ in range(world_size)] if rank == 0 else None
+        recv_device = "cpu" if host_staging else device
+        self.recv = [torch.zeros(n, dtype=torch.float32, device=recv_device) for _ in range(world_size)] if rank == 0 else None
+        self.stage = torch.zeros(n, dtype=torch.float32, device=device) if (host_staging and rank == 0) else None
 
     def gather(self):
         import torch
         import torch.distributed as dist
         self.shader.pack_tiles(self.send.data_ptr())          # synchronises the renderer's stream
-        dist.gather(self.send, self.recv, dst=0, group=self.group)
+        if self.host_staging:
+            dist.gather(self.send.cpu(), self.recv, dst=0, group=self.group)
+        else:
+            dist.gather(self.send, self.recv, dst=0, group=self.group)
         if self.rank == 0:
             torch.cuda.current_stream().synchronize()
             for src in range(1, self.world):
-                self.shader.unpack_tiles(self.recv[src].data_ptr(), src)
+                buf = self.recv[src]
+                if self.host_staging:
+                    self.stage.copy_(buf)
+                    torch.cuda.current_stream().synchronize()
+                    buf = self.stage
+                self.shader.unpack_tiles(buf.data_ptr(), src)
