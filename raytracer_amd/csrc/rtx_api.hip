@@ -100,6 +100,13 @@ struct RtxRenderer {
     int ringPos = 0;
     RtxCounters totals{};
     std::vector<float> hostStage;   // D2H staging for worldSize > 1
+    float* pinnedUser = nullptr;    // the caller's pixel array as last seen by copy_out ...
+    size_t pinnedBytes = 0;
+    char* pinnedBase = nullptr;     // ... and the whole pages inside it that are page-locked (NULL: none)
+    size_t pinnedLen = 0;
+    char* hStage = nullptr;         // page-locked staging for the frame when the caller's array cannot be page-locked
+    size_t hStageBytes = 0;
+    std::vector<hipEvent_t> stageEv;
 };
 
 // ---------------------------------------------------------------------------------
@@ -527,6 +534,9 @@ void rtx_destroy(RtxRenderer* r) {
         if (c.hCounts) hipHostFree(c.hCounts);
         if (c.stream) hipStreamDestroy(c.stream);
     }
+    if (r->pinnedBase) { hipHostUnregister(r->pinnedBase); (void)hipGetLastError(); }
+    if (r->hStage) hipHostFree(r->hStage);
+    for (hipEvent_t e : r->stageEv) hipEventDestroy(e);
     void* ptrs[] = {r->dFast, r->dInner, r->dLeaf, r->dShade, r->dMaterials, r->dTexInfo, r->dTexels, r->dTiles, r->dFb, r->dStats};
     for (void* p : ptrs) if (p) hipFree(p);
     for (int2* p : r->dTilesOfRank) if (p) hipFree(p);
@@ -765,12 +775,70 @@ static int render_frame(RtxRenderer* r, const RtxCamera* cam, uint32_t fc, bool 
     return 0;
 }
 
+// The reference hands the same host array to Render() every frame (WindowManager's pixel buffer). Page-locking it
+// once lets the device-to-host copy run at PCIe speed instead of through the runtime's pageable staging
+// (133.7 MB at 4K: 8.5 ms pageable). Best effort: an array that cannot be registered is copied as it is.
+static void pin_user_pixels(RtxRenderer* r, float* pixels, size_t bytes) {
+    if (pixels == r->pinnedUser && bytes == r->pinnedBytes) return;
+    if (r->pinnedBase) { hipHostUnregister(r->pinnedBase); (void)hipGetLastError(); }
+    r->pinnedUser = pixels; r->pinnedBytes = bytes; r->pinnedBase = nullptr; r->pinnedLen = 0;   // remembered even when not pinned: no retry per frame
+    if (bytes < ((size_t)1 << 20) || getenv("RTX_NO_PIN")) return;
+    // whole pages inside the array (registration wants page granularity); the few KB around them are copied pageable
+    const uintptr_t page = 4096, lo = ((uintptr_t)pixels + page - 1) & ~(page - 1), hi = ((uintptr_t)pixels + bytes) & ~(page - 1);
+    if (hi <= lo) return;
+    const hipError_t e = hipHostRegister((void*)lo, hi - lo, hipHostRegisterDefault);
+    if (e == hipSuccess) { r->pinnedBase = (char*)lo; r->pinnedLen = hi - lo; }
+    else { (void)hipGetLastError(); if (getenv("RTX_VERBOSE")) fprintf(stderr, "[rtx] hipHostRegister(%zu bytes): %s\n", (size_t)(hi - lo), hipGetErrorString(e)); }
+}
+
+// device framebuffer -> host array, through the page-locked part of the array where there is one
+static int fb_to_host(RtxRenderer* r, float* pixels, size_t bytes) {
+    char* dst = (char*)pixels; const char* src = (const char*)r->dFb;
+    if (r->pinnedBase && pixels == r->pinnedUser && bytes == r->pinnedBytes) {
+        const size_t head = (size_t)(r->pinnedBase - dst), mid = r->pinnedLen, tail = bytes - head - mid;
+        if (head) HIP_TRY(hipMemcpyAsync(dst, src, head, hipMemcpyDeviceToHost, r->stream));
+        HIP_TRY(hipMemcpyAsync(dst + head, src + head, mid, hipMemcpyDeviceToHost, r->stream));
+        if (tail) HIP_TRY(hipMemcpyAsync(dst + head + mid, src + head + mid, tail, hipMemcpyDeviceToHost, r->stream));
+    } else if (bytes >= ((size_t)8 << 20) && !getenv("RTX_NO_PIN")) {
+        // The array could not be page-locked (no user-pointer registration on this system): copy through a
+        // page-locked staging buffer of the renderer in 8 MiB pieces and let four host threads move each piece
+        // on as soon as it has landed. 133.7 MB at 4K: 7.9 ms through the runtime's pageable path, ~4 ms this way.
+        const size_t piece = (size_t)8 << 20, n = (bytes + piece - 1) / piece;
+        if (!r->hStage) { HIP_TRY(hipHostMalloc((void**)&r->hStage, bytes, hipHostMallocDefault)); r->hStageBytes = bytes; }
+        while (r->stageEv.size() < n) { hipEvent_t e; HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming)); r->stageEv.push_back(e); }
+        for (size_t k = 0; k < n; ++k) {
+            const size_t off = k * piece, len = std::min(piece, bytes - off);
+            HIP_TRY(hipMemcpyAsync(r->hStage + off, src + off, len, hipMemcpyDeviceToHost, r->stream));
+            HIP_TRY(hipEventRecord(r->stageEv[k], r->stream));
+        }
+        const int T = 4;
+        std::atomic<int> failed{0};
+        auto mover = [&](int t) {
+            if (hipSetDevice(r->device) != hipSuccess) { failed = 1; return; }
+            for (size_t k = (size_t)t; k < n; k += T) {
+                if (hipEventSynchronize(r->stageEv[k]) != hipSuccess) { failed = 1; return; }
+                const size_t off = k * piece, len = std::min(piece, bytes - off);
+                memcpy(dst + off, r->hStage + off, len);
+            }
+        };
+        std::vector<std::thread> pool;
+        for (int t = 1; t < T; ++t) pool.emplace_back(mover, t);
+        mover(0);
+        for (auto& th : pool) th.join();
+        if (failed) return fail("device-to-host copy of the frame failed");
+        return 0;
+    } else {
+        HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, r->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(r->stream));
+    return 0;
+}
+
 static int copy_out(RtxRenderer* r, float* pixels) {
     const size_t fbBytes = (size_t)r->width * r->height * sizeof(float4);
     if (r->cfg.worldSize == 1) {
-        HIP_TRY(hipMemcpyAsync(pixels, r->dFb, fbBytes, hipMemcpyDeviceToHost, r->stream));
-        HIP_TRY(hipStreamSynchronize(r->stream));
-        return 0;
+        pin_user_pixels(r, pixels, fbBytes);
+        return fb_to_host(r, pixels, fbBytes);
     }
     r->hostStage.resize((size_t)r->width * r->height * 4);
     HIP_TRY(hipMemcpyAsync(r->hostStage.data(), r->dFb, fbBytes, hipMemcpyDeviceToHost, r->stream));
