@@ -947,9 +947,9 @@ int rtx_download_pixels(RtxRenderer* r, float* pixels) {
     if (!r || !pixels) return fail("NULL argument");
     HIP_TRY(hipSetDevice(r->device));
     if (sync_all(r)) return 1;
-    HIP_TRY(hipMemcpyAsync(pixels, r->dFb, (size_t)r->width * r->height * sizeof(float4), hipMemcpyDeviceToHost, r->stream));
-    HIP_TRY(hipStreamSynchronize(r->stream));
-    return 0;
+    const size_t bytes = (size_t)r->width * r->height * sizeof(float4);
+    pin_user_pixels(r, pixels, bytes);
+    return fb_to_host(r, pixels, bytes);
 }
 int rtx_clear_pixels(RtxRenderer* r) {
     if (!r) return fail("NULL argument");
