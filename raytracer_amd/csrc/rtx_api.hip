@@ -100,11 +100,7 @@ struct RtxRenderer {
     int ringPos = 0;
     RtxCounters totals{};
     std::vector<float> hostStage;   // D2H staging for worldSize > 1
-    float* pinnedUser = nullptr;    // the caller's pixel array as last seen by copy_out ...
-    size_t pinnedBytes = 0;
-    char* pinnedBase = nullptr;     // ... and the whole pages inside it that are page-locked (NULL: none)
-    size_t pinnedLen = 0;
-    char* hStage = nullptr;         // page-locked staging for the frame when the caller's array cannot be page-locked
+    char* hStage = nullptr;         // page-locked staging for delivering the frame to a (pageable) host array
     size_t hStageBytes = 0;
     std::vector<hipEvent_t> stageEv;
 };
@@ -534,7 +530,6 @@ void rtx_destroy(RtxRenderer* r) {
         if (c.hCounts) hipHostFree(c.hCounts);
         if (c.stream) hipStreamDestroy(c.stream);
     }
-    if (r->pinnedBase) { hipHostUnregister(r->pinnedBase); (void)hipGetLastError(); }
     if (r->hStage) hipHostFree(r->hStage);
     for (hipEvent_t e : r->stageEv) hipEventDestroy(e);
     void* ptrs[] = {r->dFast, r->dInner, r->dLeaf, r->dShade, r->dMaterials, r->dTexInfo, r->dTexels, r->dTiles, r->dFb, r->dStats};
@@ -775,34 +770,14 @@ static int render_frame(RtxRenderer* r, const RtxCamera* cam, uint32_t fc, bool 
     return 0;
 }
 
-// The reference hands the same host array to Render() every frame (WindowManager's pixel buffer). Page-locking it
-// once lets the device-to-host copy run at PCIe speed instead of through the runtime's pageable staging
-// (133.7 MB at 4K: 8.5 ms pageable). Best effort: an array that cannot be registered is copied as it is.
-static void pin_user_pixels(RtxRenderer* r, float* pixels, size_t bytes) {
-    if (pixels == r->pinnedUser && bytes == r->pinnedBytes) return;
-    if (r->pinnedBase) { hipHostUnregister(r->pinnedBase); (void)hipGetLastError(); }
-    r->pinnedUser = pixels; r->pinnedBytes = bytes; r->pinnedBase = nullptr; r->pinnedLen = 0;   // remembered even when not pinned: no retry per frame
-    if (bytes < ((size_t)1 << 20) || getenv("RTX_NO_PIN")) return;
-    // whole pages inside the array (registration wants page granularity); the few KB around them are copied pageable
-    const uintptr_t page = 4096, lo = ((uintptr_t)pixels + page - 1) & ~(page - 1), hi = ((uintptr_t)pixels + bytes) & ~(page - 1);
-    if (hi <= lo) return;
-    const hipError_t e = hipHostRegister((void*)lo, hi - lo, hipHostRegisterDefault);
-    if (e == hipSuccess) { r->pinnedBase = (char*)lo; r->pinnedLen = hi - lo; }
-    else { (void)hipGetLastError(); if (getenv("RTX_VERBOSE")) fprintf(stderr, "[rtx] hipHostRegister(%zu bytes): %s\n", (size_t)(hi - lo), hipGetErrorString(e)); }
-}
-
-// device framebuffer -> host array, through the page-locked part of the array where there is one
+// device framebuffer -> host array
 static int fb_to_host(RtxRenderer* r, float* pixels, size_t bytes) {
     char* dst = (char*)pixels; const char* src = (const char*)r->dFb;
-    if (r->pinnedBase && pixels == r->pinnedUser && bytes == r->pinnedBytes) {
-        const size_t head = (size_t)(r->pinnedBase - dst), mid = r->pinnedLen, tail = bytes - head - mid;
-        if (head) HIP_TRY(hipMemcpyAsync(dst, src, head, hipMemcpyDeviceToHost, r->stream));
-        HIP_TRY(hipMemcpyAsync(dst + head, src + head, mid, hipMemcpyDeviceToHost, r->stream));
-        if (tail) HIP_TRY(hipMemcpyAsync(dst + head + mid, src + head + mid, tail, hipMemcpyDeviceToHost, r->stream));
-    } else if (bytes >= ((size_t)8 << 20) && !getenv("RTX_NO_PIN")) {
-        // The array could not be page-locked (no user-pointer registration on this system): copy through a
-        // page-locked staging buffer of the renderer in 8 MiB pieces and let four host threads move each piece
-        // on as soon as it has landed. 133.7 MB at 4K: 7.9 ms through the runtime's pageable path, ~4 ms this way.
+    if (bytes >= ((size_t)8 << 20) && !getenv("RTX_PLAIN_COPY")) {
+        // The caller's array is ordinary pageable memory (page-locking it per call costs more than the copy, and
+        // caching a registration across calls would outlive the array): copy through a page-locked staging buffer
+        // of the renderer in 8 MiB pieces and let four host threads move each piece on as soon as it has landed.
+        // 133.7 MB at 4K: 8.5 ms through the runtime's pageable path, 3.0 ms this way.
         const size_t piece = (size_t)8 << 20, n = (bytes + piece - 1) / piece;
         if (!r->hStage) { HIP_TRY(hipHostMalloc((void**)&r->hStage, bytes, hipHostMallocDefault)); r->hStageBytes = bytes; }
         while (r->stageEv.size() < n) { hipEvent_t e; HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming)); r->stageEv.push_back(e); }
@@ -837,7 +812,6 @@ static int fb_to_host(RtxRenderer* r, float* pixels, size_t bytes) {
 static int copy_out(RtxRenderer* r, float* pixels) {
     const size_t fbBytes = (size_t)r->width * r->height * sizeof(float4);
     if (r->cfg.worldSize == 1) {
-        pin_user_pixels(r, pixels, fbBytes);
         return fb_to_host(r, pixels, fbBytes);
     }
     r->hostStage.resize((size_t)r->width * r->height * 4);
@@ -948,7 +922,6 @@ int rtx_download_pixels(RtxRenderer* r, float* pixels) {
     HIP_TRY(hipSetDevice(r->device));
     if (sync_all(r)) return 1;
     const size_t bytes = (size_t)r->width * r->height * sizeof(float4);
-    pin_user_pixels(r, pixels, bytes);
     return fb_to_host(r, pixels, bytes);
 }
 int rtx_clear_pixels(RtxRenderer* r) {
