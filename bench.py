@@ -74,7 +74,10 @@ def main():
     if backend != "nccl":
         local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # RTX_BENCH_FORCE_DIST=1 takes the process-group path with a single rank too (a one-GPU check that RCCL
+    # initialises next to the renderer's own streams and that the gather runs).
+    use_dist = world > 1 or os.environ.get("RTX_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
@@ -97,7 +100,7 @@ def main():
                        frames_in_flight=args.frames_in_flight)
     t_create = time.time() - t0
     W, H = shader.width, shader.height
-    gather = DeviceGather(shader, rank, world, torch.device("cuda", local_rank), host_staging=backend != "nccl") if world > 1 else None
+    gather = DeviceGather(shader, rank, world, torch.device("cuda", local_rank), host_staging=backend != "nccl") if use_dist else None
     cam = scene.camera
 
     def step(i):
@@ -110,7 +113,7 @@ def main():
             shader.Render(None, cam)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
         shader.counters()            # synchronises the renderer's own stream
@@ -129,14 +132,14 @@ def main():
         gather.gather()                # one exchange per delivered frame batch
     c = shader.counters()              # stream sync
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
 
     rays_local = float(c.rays)
     t = torch.tensor([elapsed], dtype=torch.float64, device=red_device)
     rsum = torch.tensor([rays_local], dtype=torch.float64, device=red_device)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(rsum, op=dist.ReduceOp.SUM)
     elapsed = float(t.item())
@@ -256,10 +259,10 @@ def main():
                "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": args.workload, "triangles": ntri, "resolution": [W, H], "bounces": 4,
                           "spp_per_step": 1, "traversal": args.traversal, "partition": f"tiles64x32 round-robin x{world}",
-                          "camera": "orbit" if args.orbit else "fixed", "collective": backend if world > 1 else None, "frames_in_flight": args.frames_in_flight or 6, "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES")},
+                          "camera": "orbit" if args.orbit else "fixed", "collective": backend if use_dist else None, "frames_in_flight": args.frames_in_flight or 6, "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES")},
                "roofline": roofline, "cpu_baseline": cpu, "extra": extra}
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -259,8 +259,11 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_trace(DevScene sc, const float4* 
 // lanes are idle (or the whole wave is) they pull the next rays of the queue — ballot + prefix
 // popcount over the idle mask, one device atomic per RTX_RESERVE rays — so the traversal loop keeps
 // running on well-filled waves. Per-ray results do not depend on which lane traced them.
+// RTX_REFILL_MIN = 32 measured best (8: +5 %, 16: +3 %, 24: +1.5 %, 40: +5 %, 48: +9 % on the bounce-1
+// launch): a refill stalls the wave for a memory round trip; running one pass between the issue of
+// the new rays' loads and their first use was tried and cost more (registers) than it hid.
 #ifndef RTX_REFILL_MIN
-#define RTX_REFILL_MIN 16
+#define RTX_REFILL_MIN 32
 #endif
 #ifndef RTX_RESERVE
 #define RTX_RESERVE 64u
@@ -351,26 +354,13 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_trace_refill(DevScene sc, const f
         do {
             if (COUNT) wp++;
             if (cur != RTX_IDLE) {
-                bool finished = false;
-                if (cur == RTX_NEED_POP) {
-                    finished = true;
-                    while (st.sp > 0) {
-                        int ref; float tn;
-                        st.pop(ref, tn);
-                        if (!(tn > limit)) { cur = ref; finished = false; break; }
-                    }
-                }
-                if (finished) {
-                    hitT[q] = best.t; hitLeaf[q] = best.leaf;
-                    cur = RTX_IDLE;
-                } else {
-                  if (cur >= 0) {
+                if (cur >= 0) {
                     if (COUNT) ic++;
                     cur = wide_step<false, BIG>(nodes, cur, w, limit, st);
-                  }
-                  // not "else": a lane whose step ends at a leaf tests it in this same pass — the leaf
-                  // section runs in practically every pass anyway (some lane of the 64 is at a leaf)
-                  if (cur < 0 && cur != RTX_NEED_POP) {
+                }
+                // not "else": a lane whose step ends at a leaf tests it in this same pass — the leaf
+                // section runs in practically every pass anyway (some lane of the 64 is at a leaf)
+                if (cur < 0 && cur != RTX_NEED_POP) {
                     int leafIdx = ~cur, box;
                     float t = intersect_leaf(sc.leaf, leafIdx, w.a.x, w.a.y, w.b.x, dx, dy, dz, box);
                     if (COUNT) lc++;
@@ -379,7 +369,21 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_trace_refill(DevScene sc, const f
                         limit = t + t * RTX_CULL_SLACK;
                     }
                     cur = RTX_NEED_POP;
-                  }
+                }
+                // the pop closes the pass (entries beyond the current hit are dropped in a loop, they
+                // cost no pass of their own), so a lane whose stack runs empty goes idle — and counts
+                // towards the next refill — one pass earlier than if it popped at the start of the next
+                if (cur == RTX_NEED_POP) {
+                    bool finished = true;
+                    while (st.sp > 0) {
+                        int ref; float tn;
+                        st.pop(ref, tn);
+                        if (!(tn > limit)) { cur = ref; finished = false; break; }
+                    }
+                    if (finished) {
+                        hitT[q] = best.t; hitLeaf[q] = best.leaf;
+                        cur = RTX_IDLE;
+                    }
                 }
             }
             nIdle = __popcll(__ballot(cur == RTX_IDLE));
