@@ -70,6 +70,9 @@ def ref_parts():
         L.ref_vec_ops.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]
         L.ref_vec_geom.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]
         L.ref_color_ops.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]
+        if hasattr(L, "ref_read_bmp"):
+            L.ref_read_bmp.argtypes = [C.c_char_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_void_p, C.c_uint64]
+            L.ref_read_bmp.restype = C.c_uint64
         _ref = L
     return _ref
 

@@ -6,19 +6,20 @@
  * oracle/_ref/libref_parts.so, which is git-ignored. The reference sources are
  * compiled WHERE THEY LIE under $(REF)/src — nothing is copied into the repo:
  *     Shading.h, Camera.h, Vector3.h, Color.h, Material.h, Object.h, Texture.h,
- *     SpatialType.h, Random.h  (included below by path)
- *     Random.cpp               (compiled as its own translation unit)
+ *     SpatialType.h, Random.h, BitmapReader.h  (included below by path)
+ *     Random.cpp, BitmapReader.cpp             (compiled as their own translation units)
  *
  * What is NOT here, and why: ThreadedShader.cpp, BVHTree.cpp and the
  * serializers all include RenderingContext.h, which includes <GL/glew.h> and
  * <GLFW/glfw3.h> (src/RenderingContext.h:10-11). Neither header exists in this
  * image and stand-ins are not allowed, so those files are unbuildable here;
  * rt_oracle.cpp restates them and is pinned by recorded reference outputs
- * instead (tests/test_oracle_pins.py).
+ * instead (tests/test_oracle.py).
  */
 #include "Shading.h"   // -I$(REF)/src
 #include "Camera.h"
 #include "Random.h"
+#include "BitmapReader.h"
 
 #include <cstdint>
 #include <cstring>
@@ -86,6 +87,20 @@ void ref_color_ops(const float* a4, const float* b4, float t, float* out /* 3 x 
     Color r[3];
     r[0] = Color::Lerp(a, b, t); r[1] = Color::Clamp(a); r[2] = a * b;
     memcpy(out, r, sizeof(r));
+}
+
+// BitmapReader::ReadFile (src/BitmapReader.cpp:70-137): texels as the reference unpacks them
+// (R | G<<8 | B<<16 | 255<<24, rows in file order). Returns the texel count, 0 if the reader
+// rejects the file; copies at most `cap` texels. The checksum is not exported: the reference
+// accumulates it into an uninitialised field (src/BitmapReader.cpp:129-134,168).
+uint64_t ref_read_bmp(const char* path, uint32_t* width, uint32_t* height, uint32_t* texels, uint64_t cap) {
+    Image im = BitmapReader::ReadFile(path);
+    if (!im.data) return 0;
+    *width = im.width; *height = im.height;
+    const uint64_t n = (uint64_t)im.width * im.height;
+    memcpy(texels, im.data, (n < cap ? n : cap) * sizeof(uint32_t));
+    delete[] im.data;
+    return n;
 }
 
 } // extern "C"

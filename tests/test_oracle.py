@@ -126,6 +126,28 @@ def test_texture_fetch_bit_exact(scene1):
 
 
 @pytest.mark.skipif(not have_reference(), reason="needs /root/reference (build container only)")
+@needs_ref
+@pytest.mark.skipif(not have_reference(), reason="needs the bundled textures under /root/reference")
+@pytest.mark.parametrize("name", ["dunes.bmp", "metal.bmp", "sand.bmp"])
+def test_bitmap_ingest_matches_the_reference_reader(name, tmp_path):
+    """Our .bmp ingest (host/ingest.cpp read_bmp, reached through a .mtl's map_Ka like
+    src/MaterialSerializer.cpp:215-219) against the reference's own BitmapReader::ReadFile
+    (src/BitmapReader.cpp:70-137, compiled into libref_parts.so): same size, same texel words."""
+    from raytracer_amd.scene import HostScene
+    bmp = os.path.join(REFERENCE, "resources/textures", name)
+    w, h = C.c_uint32(0), C.c_uint32(0)
+    cap = 2048 * 2048
+    want = np.zeros(cap, dtype=np.uint32)
+    n = ref.ref_read_bmp(bmp.encode(), C.byref(w), C.byref(h), want.ctypes.data, cap)
+    assert 0 < n <= cap
+    (tmp_path / "one.mtl").write_text(f"newmtl A\nmap_Ka {os.path.relpath(bmp, tmp_path)}\n")
+    s = HostScene(128, 128).load_mtl(str(tmp_path / "one.mtl"))
+    info = s.texture_info[-1]
+    assert (int(info["width"]), int(info["height"])) == (w.value, h.value)
+    got = s.texture_data[int(info["offset"]):int(info["offset"]) + n]
+    assert np.array_equal(got, want[:n])
+
+
 def test_recorded_reference_outputs_2scn():
     """BASELINE.md §2 / SURVEY.md §8c: the reference's own strict (-O2) build on
     resources/scenes/2.scn gave 550 050 primary hits of 984 064 pixels at 992x992, frame 0
