@@ -29,8 +29,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 # frames are queued several deep, one stream each: give the process a hardware queue per stream
 # (HIP reads this once, when the process first touches the GPU; the usual value is 4)
-if int(os.environ.get("GPU_MAX_HW_QUEUES", "4")) < 8:
-    os.environ["GPU_MAX_HW_QUEUES"] = "8"
+if int(os.environ.get("GPU_MAX_HW_QUEUES", "4")) < 16:
+    os.environ["GPU_MAX_HW_QUEUES"] = "16"
 
 WORKLOADS = {
     # name: (triangles, width, height, textured)
@@ -45,14 +45,14 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=32)
+    ap.add_argument("--steps", type=int, default=64)
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--workload", default="cfg4_10Mtri_4k", choices=sorted(WORKLOADS))
     ap.add_argument("--traversal", default="culled", choices=["culled", "exact"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--frames-in-flight", type=int, default=0,
-                    help="RtxConfig.framesInFlight for the timed region: 0 = library default (6 with the 8 hardware queues set above), "
+                    help="RtxConfig.framesInFlight for the timed region: 0 = library default (14 with the 16 hardware queues set above), "
                          "1 = strictly serial frames")
     ap.add_argument("--d2h", action="store_true", help="also time K frames with the host copy (reported in `extra`)")
     ap.add_argument("--orbit", action="store_true", help="-O camera: new camera + frameCounter=0 every frame (src/Main.cpp:68-82)")
@@ -259,7 +259,7 @@ def main():
                "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": args.workload, "triangles": ntri, "resolution": [W, H], "bounces": 4,
                           "spp_per_step": 1, "traversal": args.traversal, "partition": f"tiles64x32 round-robin x{world}",
-                          "camera": "orbit" if args.orbit else "fixed", "collective": backend if use_dist else None, "frames_in_flight": args.frames_in_flight or 6, "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES")},
+                          "camera": "orbit" if args.orbit else "fixed", "collective": backend if use_dist else None, "frames_in_flight": args.frames_in_flight or 14, "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES")},
                "roofline": roofline, "cpu_baseline": cpu, "extra": extra}
         print(json.dumps(out), flush=True)
     if use_dist:

@@ -138,7 +138,9 @@ typedef struct RtxConfig {
                               pixels_rgba == NULL (each has its own stream and path state; the running
                               mean is still updated in frame order); 1 = strictly serial; 0 -> as many as the
                               process has hardware queues for: 3 with HIP's default GPU_MAX_HW_QUEUES=4,
-                              6 with GPU_MAX_HW_QUEUES=8 (an environment variable HIP reads at start-up) */
+                              6 with GPU_MAX_HW_QUEUES=8, 14 with 16 (an environment variable HIP reads at
+                              start-up); at most 16. Each frame in flight holds its own ray queues and path
+                              state: about 125 B per pixel of this rank's tiles */
 } RtxConfig;
 
 typedef struct RtxCounters {

@@ -29,8 +29,8 @@ static int fail(const std::string& m) { g_err = m; return 1; }
         if (e_ != hipSuccess) return fail(std::string(#expr) + ": " + hipGetErrorString(e_)); \
     } while (0)
 
-static const int kRing = 16;      // frames whose timing events are kept; a frame's timing is read kLag frames later
-static const int kLag = 8;
+static const int kRing = 32;      // frames whose timing events are kept; a frame's timing is read kLag frames later
+static const int kLag = 16;
 static const int kEvents = 10;    // start + one per kernel (8) + end
 
 struct RtxRenderer {
@@ -668,10 +668,12 @@ int rtx_create(const RtxSceneDesc* scene, const RtxConfig* cfgIn, RtxRenderer** 
     if (culled) r->ldsSlow = (size_t)std::max(2, flat.maxDepth + 2) * RTX_BLOCK * sizeof(int);
     // Streams beyond the hardware queues of the process share a queue and serialise (measured: 4 frames on the
     // default 4 queues are slower than 3), so the default depth follows GPU_MAX_HW_QUEUES, which HIP reads when
-    // the process initialises it: 3 frames on 4 queues, 6 on 8.
+    // the process initialises it: 3 frames on 4 queues, 6 on 8, 14 on 16 (deeper pipelines matter most when the
+    // queues are short — a rank's share of the tiles on a multi-GPU run: 1/8 of a 4K frame takes 1.33 ms per
+    // frame with 6 in flight and 1.17 ms with 14).
     int hwQueues = 4;
     if (const char* e = getenv("GPU_MAX_HW_QUEUES")) hwQueues = std::max(1, atoi(e));
-    int depth = cfg.framesInFlight > 0 ? cfg.framesInFlight : (hwQueues <= 4 ? std::max(1, hwQueues - 1) : std::min(hwQueues - 2, 8));
+    int depth = cfg.framesInFlight > 0 ? cfg.framesInFlight : (hwQueues <= 4 ? std::max(1, hwQueues - 1) : std::min(hwQueues - 2, 14));
     if (const char* e = getenv("RTX_FRAMES_IN_FLIGHT")) depth = atoi(e);
     depth = std::max(1, std::min(depth, kLag));
     r->ctx.resize((size_t)depth);
