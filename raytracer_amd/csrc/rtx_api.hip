@@ -122,26 +122,33 @@ inline float i2f(int32_t v) { float f; memcpy(&f, &v, 4); return f; }
 
 void emit_leaf(const RtxObject& o, int32_t objectID, int32_t boxID, float4* leaf, float4* shade) {
     const RtxVec4 A = o.vertices[0], B = o.vertices[1], C = o.vertices[2];
+    float4 old[4];      // the shading record keeps (e2.z objectID boxID type) / (B.x B.y C.x C.y) in its third and fourth quad
     if (o.type == RTX_TRIANGLE) {
         // e1 = B - A, e2 = C - A: the same two subtractions the reference performs
         // first in IntersectTriangle (src/ThreadedShader.cpp:298-299)
         const float e1x = B.x - A.x, e1y = B.y - A.y, e1z = B.z - A.z;
         const float e2x = C.x - A.x, e2y = C.y - A.y, e2z = C.z - A.z;
-        leaf[0] = make_float4(A.x, A.y, A.z, e1x);
-        leaf[1] = make_float4(e1y, e1z, e2x, e2y);
-        leaf[2] = make_float4(e2z, i2f(objectID), i2f(boxID), i2f(o.type));
-        leaf[3] = make_float4(B.x, B.y, C.x, C.y);
+        old[0] = make_float4(A.x, A.y, A.z, e1x);
+        old[1] = make_float4(e1y, e1z, e2x, e2y);
+        old[2] = make_float4(e2z, i2f(objectID), i2f(boxID), i2f(o.type));
+        old[3] = make_float4(B.x, B.y, C.x, C.y);
     } else {
-        leaf[0] = make_float4(o.position.x, o.position.y, o.position.z, o.radius);
-        leaf[1] = make_float4(0, 0, 0, 0);
-        leaf[2] = make_float4(0, i2f(objectID), i2f(boxID), i2f(o.type));
-        leaf[3] = make_float4(0, 0, 0, 0);
+        old[0] = make_float4(o.position.x, o.position.y, o.position.z, o.radius);
+        old[1] = make_float4(0, 0, 0, 0);
+        old[2] = make_float4(0, i2f(objectID), i2f(boxID), i2f(o.type));
+        old[3] = make_float4(0, 0, 0, 0);
     }
+    // traversal record: the primitive, then boxID and type in one word, so that a leaf test reads 40 contiguous bytes
+    const int32_t tag = (int32_t)(((uint32_t)boxID << 3) | ((uint32_t)o.type & 7u));
+    leaf[0] = old[0];
+    leaf[1] = old[1];
+    leaf[2] = make_float4(old[2].x, i2f(tag), 0.0f, 0.0f);
+    leaf[3] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     const RtxVec4 n0 = o.normals[0], n1 = o.normals[1], n2 = o.normals[2];
-    // the shading record is one 128-byte line of its own: a copy of the leaf record (hit_normal needs the
+    // the shading record is one 128-byte line of its own: the primitive (hit_normal needs the
     // vertices) followed by the normals and the material, so that k_shade touches ONE scattered line per hit
     // instead of a leaf line plus a 48-byte record that straddles lines a third of the time
-    for (int k = 0; k < 4; ++k) shade[k] = leaf[k];
+    for (int k = 0; k < 4; ++k) shade[k] = old[k];
     shade[4] = make_float4(n0.x, n0.y, n0.z, n1.x);
     shade[5] = make_float4(n1.y, n1.z, n2.x, n2.y);
     shade[6] = make_float4(n2.z, i2f(o.materialID), 0, 0);
@@ -582,7 +589,8 @@ int rtx_create(const RtxSceneDesc* scene, const RtxConfig* cfgIn, RtxRenderer** 
     r->linear = !useBVH;
     // distance culling needs boxes that contain their descendants; otherwise keep the reference's visit set
     r->mode = r->linear ? RTX_MODE_LINEAR : ((cfg.traversal == RTX_TRAVERSE_EXACT || !flat.nested || flat.fast.empty()) ? RTX_MODE_EXACT : RTX_MODE_CULLED);
-    if (r->mode == RTX_MODE_CULLED && (flat.fast.size() > ((size_t)1 << 25) || getenv("RTX_FORCE_BIG"))) r->mode = RTX_MODE_CULLED_BIG;
+    const size_t bigNodes = (size_t)1 << 25;
+    if (r->mode == RTX_MODE_CULLED && (flat.fast.size() > bigNodes || getenv("RTX_FORCE_BIG"))) r->mode = RTX_MODE_CULLED_BIG;
     const bool culled = r->mode == RTX_MODE_CULLED || r->mode == RTX_MODE_CULLED_BIG;
     r->tileW = cfg.tileW; r->tileH = cfg.tileH;
 

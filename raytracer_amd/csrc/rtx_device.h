@@ -5,10 +5,10 @@
 //   fast[]    64 B / inner node : same leaves indexed by a binned-SAH tree built in rtx_create (rtx_build.h)
 //             q0 = (lo0.x lo0.y lo0.z hi0.x) q1 = (hi0.y hi0.z lo1.x lo1.y)
 //             q2 = (lo1.z hi1.x hi1.y hi1.z) q3 = (ref0 ref1 - -)      ref>=0 inner, ref<0 leaf ~ref
-//   leaf[]    64 B / primitive  : q0 = (A.x A.y A.z e1.x) q1 = (e1.y e1.z e2.x e2.y)
-//             q2 = (e2.z objectID boxID type)  q3 = (B.x B.y C.x C.y)   [q3 only read when shading]
-//             sphere: A = centre, e1.x = radius
-//   shade[]  128 B / primitive  : q0..q3 = copy of the leaf record, q4 = (n0.x n0.y n0.z n1.x) q5 = (n1.y n1.z n2.x n2.y)
+//   leaf[]    64 B / primitive  : q0 = (A.x A.y A.z e1.x) q1 = (e1.y e1.z e2.x e2.y) q2 = (e2.z boxID<<3|type - -)
+//             sphere: A = centre, e1.x = radius. A leaf test reads the first 40 bytes (three lane loads).
+//   shade[]  128 B / primitive  : q0 q1 as in leaf[], q2 = (e2.z objectID boxID type) q3 = (B.x B.y C.x C.y),
+//                                 q4 = (n0.x n0.y n0.z n1.x) q5 = (n1.y n1.z n2.x n2.y)
 //                                 q6 = (n2.z materialID - -) q7 unused: one line per shaded hit
 //   materials 128 B each, reference layout (src/Material.h:7-25)
 // One inner visit = one 64-byte line (the reference touches three: the node and

@@ -531,7 +531,7 @@ __global__ void k_hits_to_ids(DevScene sc, DevFrame fr, const int2* __restrict__
     if (!slot_to_pixel(fr, tiles, slot, x, y)) return;
     int leaf = hitLeaf[slot];
     int id = -1;
-    if (leaf >= 0) id = __float_as_int(sc.leaf[(size_t)leaf * 4 + 2].y);
+    if (leaf >= 0) id = __float_as_int(sc.shade[(size_t)leaf * 8 + 2].y);
     ids[(size_t)y * fr.width + x] = id;
 }
 
@@ -544,7 +544,7 @@ __global__ void k_probe_finish(DevScene sc, int linearMode, const float4* __rest
     int id = -1; F4 point = mk4(0, 0, 0), normal = mk4(0, 0, 0);
     if (leaf >= 0) {
         HitPrim prim = load_prim(sc, leaf);
-        id = __float_as_int(sc.leaf[(size_t)leaf * 4 + 2].y);
+        id = __float_as_int(sc.shade[(size_t)leaf * 8 + 2].y);
         float4 o4 = rqO[q], d4 = rqD[q];
         F4 o = mk4(o4.x, o4.y, o4.z), d = mk4(d4.x, d4.y, d4.z);
         F4 dirForPoint = linearMode ? mul4(d, 1.0000001f) : d;

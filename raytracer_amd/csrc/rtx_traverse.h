@@ -74,15 +74,20 @@ __device__ __forceinline__ float intersect_sphere(float ox, float oy, float oz, 
     return fminf(t1, t2);
 }
 
+// Leaf record (rtx_device.h): q0 = (A.xyz e1.x) q1 = (e1.yz e2.xy) q2 = (e2.z boxID<<3|type - -) q3 unused.
+// What a primitive test needs sits in the first 40 bytes: three lane loads (16 + 16 + 8 bytes) — the
+// traversal kernels are bound by the number of lane loads the vector L1 accepts.
 __device__ __forceinline__ float intersect_leaf(const float4* __restrict__ leafBase, int leafIdx,
                                                 float ox, float oy, float oz, float dx, float dy, float dz,
                                                 int& boxOut) {
     const float4* L = leafBase + (size_t)leafIdx * 4;
-    float4 q0 = L[0], q1 = L[1], q2 = L[2];
-    boxOut = __float_as_int(q2.z);
-    int type = __float_as_int(q2.w);
-    if (type == 4 /* RTX_TRIANGLE */)
-        return intersect_triangle(ox, oy, oz, dx, dy, dz, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x);
+    float4 q0 = L[0], q1 = L[1];
+    const float2 q2 = *(const float2*)(L + 2);
+    const float e2z = q2.x;
+    const int tag = __float_as_int(q2.y);
+    boxOut = tag >> 3;
+    if ((tag & 7) == 4 /* RTX_TRIANGLE */)
+        return intersect_triangle(ox, oy, oz, dx, dy, dz, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, e2z);
     return intersect_sphere(ox, oy, oz, dx, dy, dz, q0.x, q0.y, q0.z, q0.w);
 }
 
@@ -239,6 +244,24 @@ __device__ __forceinline__ rtx_f2 pk_plane_distance(rtx_f2 v, rtx_f2 oPair, rtx_
     return t;
 }
 
+// Tail of a node step: the children that passed, ordered by entry distance; all but the nearest are
+// pushed (farthest first), the nearest is returned — or RTX_NEED_POP when none passed.
+__device__ __forceinline__ int order_and_push(float t0, float t1, float t2, float t3, bool p0, bool p1, bool p2, bool p3,
+                                              const int4& rf, LaneStack& st) {
+    int r0 = rf.x, r1 = rf.y, r2 = rf.z, r3 = rf.w;
+    t0 = p0 ? t0 : INFINITY; t1 = p1 ? t1 : INFINITY; t2 = p2 ? t2 : INFINITY; t3 = p3 ? t3 : INFINITY;
+    r0 = p0 ? r0 : RTX_NEED_POP; r1 = p1 ? r1 : RTX_NEED_POP; r2 = p2 ? r2 : RTX_NEED_POP; r3 = p3 ? r3 : RTX_NEED_POP;
+    const int n = (int)p0 + (int)p1 + (int)p2 + (int)p3;
+    // a passing entry distance is finite or -inf, so misses (+inf) sort last
+    RTX_CSWAP(t0, r0, t1, r1) RTX_CSWAP(t2, r2, t3, r3) RTX_CSWAP(t0, r0, t2, r2) RTX_CSWAP(t1, r1, t3, r3) RTX_CSWAP(t1, r1, t2, r2)
+    if (n > 1) {
+        if (n > 3) st.push(r3, t3);
+        if (n > 2) st.push(r2, t2);
+        st.push(r1, t1);
+    }
+    return r0;
+}
+
 // One step through a 4-wide node: tests the four child boxes, drops those that miss or start beyond
 // `limit`, orders the rest by entry distance, pushes all but the nearest (farthest first) and returns
 // the nearest — or RTX_NEED_POP when none is left. Empty slots hold NaN boxes: their distances compare
@@ -298,18 +321,7 @@ __device__ __forceinline__ int wide_step(const float4* __restrict__ nodes, int c
     const bool p1 = t1 <= f1 && f1 > 0.0f && !(t1 > limit);
     const bool p2 = t2 <= f2 && f2 > 0.0f && !(t2 > limit);
     const bool p3 = t3 <= f3 && f3 > 0.0f && !(t3 > limit);
-    int r0 = rf.x, r1 = rf.y, r2 = rf.z, r3 = rf.w;
-    t0 = p0 ? t0 : INFINITY; t1 = p1 ? t1 : INFINITY; t2 = p2 ? t2 : INFINITY; t3 = p3 ? t3 : INFINITY;
-    r0 = p0 ? r0 : RTX_NEED_POP; r1 = p1 ? r1 : RTX_NEED_POP; r2 = p2 ? r2 : RTX_NEED_POP; r3 = p3 ? r3 : RTX_NEED_POP;
-    const int n = (int)p0 + (int)p1 + (int)p2 + (int)p3;
-    // a passing entry distance is finite or -inf, so misses (+inf) sort last
-    RTX_CSWAP(t0, r0, t1, r1) RTX_CSWAP(t2, r2, t3, r3) RTX_CSWAP(t0, r0, t2, r2) RTX_CSWAP(t1, r1, t3, r3) RTX_CSWAP(t1, r1, t2, r2)
-    if (n > 1) {
-        if (n > 3) st.push(r3, t3);
-        if (n > 2) st.push(r2, t2);
-        st.push(r1, t1);
-    }
-    return r0;
+    return order_and_push(t0, t1, t2, t3, p0, p1, p2, p3, rf, st);
 }
 
 // Fast path for clean lanes (RTX_TRAVERSE_CULLED): own 4-wide SAH tree over the reference's leaves,
