@@ -208,6 +208,16 @@ def main():
             except Exception:
                 traffic = None
         all_rays = sum(cc.raysPerBounce)
+        # What actually stops this launch is not HBM but the rate at which a CU's vector L1 accepts 16-byte lane
+        # loads (tools/tcp_rate, profiles/r01_tcp_rate.txt: 0.87 per clock per CU for this access pattern):
+        # a node step of the culled path is 7 such loads per lane, a leaf test 3.
+        props = torch.cuda.get_device_properties(local_rank)
+        clock_hz = float(getattr(props, "clock_rate", 2400000)) * 1e3
+        lane_loads = (7.0 if args.traversal == "culled" else 4.0) * inner + 3.0 * leaf
+        l1 = {"lane_loads_16B_per_launch": lane_loads,
+              "per_clock_per_cu": lane_loads / (trace_ms[b] * 1e-3 * clock_hz * props.multi_processor_count) if trace_ms[b] > 0 else 0.0,
+              "ceiling_per_clock_per_cu": 0.87, "ceiling_source": "tools/tcp_rate mode 2 (7 loads per scattered line, L2-resident)",
+              "clock_hz": clock_hz, "cus": props.multi_processor_count}
         names = (["k_primary<CULLED, count>", "k_trace_refill<count, 1>", "k_trace_refill<count, 2>", "k_trace_refill<count, 3>"]
                  if args.traversal == "culled" else ["k_primary<EXACT, count>", "k_trace<EXACT, count> bounce 1",
                                                      "k_trace<EXACT, count> bounce 2", "k_trace<EXACT, count> bounce 3"])
@@ -223,7 +233,8 @@ def main():
                     "requested_gbs": requested_bytes / (trace_ms[b] * 1e-3) / 1e9 if trace_ms[b] > 0 else 0.0,
                     "work_items_per_lane_pass": [(cc.innerVisits[i] + cc.leafTests[i]) / (64.0 * cc.wavePasses[i]) if cc.wavePasses[i] else None
                                                  for i in range(4)],
-                    "algorithmic_bytes_per_ray_all_trace": (64.0 * sum(cc.innerVisits) + 48.0 * sum(cc.leafTests)) / max(1, all_rays)}
+                    "algorithmic_bytes_per_ray_all_trace": (64.0 * sum(cc.innerVisits) + 48.0 * sum(cc.leafTests)) / max(1, all_rays),
+                    "vector_l1_front_end": l1}
         extra["serial_kernel_ms_per_frame"] = {"primary": serial_ms[0], "shade0": serial_ms[1], "trace1": serial_ms[2],
                                                "shade1": serial_ms[3], "trace2": serial_ms[4], "shade2": serial_ms[5],
                                                "trace3": serial_ms[6], "shade3": serial_ms[7]}
