@@ -200,13 +200,16 @@ def main():
         # node width, so that rounds stay comparable; the bytes the loads really request are reported beside it
         algo_bytes = 64.0 * inner + 48.0 * leaf
         achieved = algo_bytes / (trace_ms[b] * 1e-3) / 1e9 if trace_ms[b] > 0 else 0.0
-        traffic = None
+        traffic, tcp_accesses = None, None
         pmc = os.path.join(HERE, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get(args.workload, {}).get(["k_primary", "k_trace1", "k_trace2", "k_trace3"][b])
+                pj = json.load(open(pmc))
+                kname = ["k_primary", "k_trace1", "k_trace2", "k_trace3"][b]
+                traffic = pj.get(args.workload, {}).get(kname)
+                tcp_accesses = pj.get(args.workload + ":tcp_accesses", {}).get(kname)
             except Exception:
-                traffic = None
+                traffic, tcp_accesses = None, None
         all_rays = sum(cc.raysPerBounce)
         # What actually stops this launch is not HBM but the rate at which a CU's vector L1 accepts 16-byte lane
         # loads (tools/tcp_rate, profiles/r01_tcp_rate.txt: 0.87 per clock per CU for this access pattern):
@@ -214,8 +217,13 @@ def main():
         props = torch.cuda.get_device_properties(local_rank)
         clock_hz = float(getattr(props, "clock_rate", 2400000)) * 1e3
         lane_loads = (7.0 if args.traversal == "culled" else 4.0) * inner + 3.0 * leaf
-        l1 = {"lane_loads_16B_per_launch": lane_loads,
-              "per_clock_per_cu": lane_loads / (trace_ms[b] * 1e-3 * clock_hz * props.multi_processor_count) if trace_ms[b] > 0 else 0.0,
+        cu_clocks = trace_ms[b] * 1e-3 * clock_hz * props.multi_processor_count
+        l1 = {"lane_loads_issued_per_launch": lane_loads,                  # 7 I' + 3 L' from the device counters
+              # what the L1 counted for this launch (TCP_TOTAL_CACHE_ACCESSES, profiles/pmc_traffic.json): lanes of a
+              # wave that read the same address — the top of the tree — arrive merged, so this is below `issued`
+              "l1_accesses_per_launch_pmc": tcp_accesses,
+              "per_clock_per_cu": (tcp_accesses / cu_clocks) if (tcp_accesses and cu_clocks > 0) else None,
+              "issued_per_clock_per_cu": lane_loads / cu_clocks if cu_clocks > 0 else None,
               "ceiling_per_clock_per_cu": 0.87, "ceiling_source": "tools/tcp_rate mode 2 (7 loads per scattered line, L2-resident)",
               "clock_hz": clock_hz, "cus": props.multi_processor_count}
         names = (["k_primary<CULLED, count>", "k_trace_refill<count, 1>", "k_trace_refill<count, 2>", "k_trace_refill<count, 3>"]

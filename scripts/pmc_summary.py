@@ -112,7 +112,9 @@ def main():
                       "correction (128-B requests tallied at 64 B), calibrated for this access pattern with tools/gather_ceiling (7 x 16 B "
                       "from one scattered 128-B line per lane: one TCC_EA0_RDREQ and 64 B of FETCH_SIZE per line); Infinity-Cache hits "
                       "are counted, not excluded",
-             workload: {n: (hbm(ks[0]) if ks else None) for n, ks in names.items()}}
+             workload: {n: (hbm(ks[0]) if ks else None) for n, ks in names.items()},
+             # accesses the vector L1 (TCP) counted for the same launches: lanes of a wave that read one address are merged
+             workload + ":tcp_accesses": {n: (out.get(ks[0], {}).get("TCP_TOTAL_CACHE_ACCESSES_sum") if ks else None) for n, ks in names.items()}}
         open(sys.argv[3], "w").write(json.dumps(t, indent=1) + "\n")
     for k in sorted(out, key=lambda k: -out[k].get("total_ms", 0)):
         o = out[k]

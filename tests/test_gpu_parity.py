@@ -296,13 +296,13 @@ def test_wave_pass_counter_and_queue_holes(synth_small):
 
 
 def test_frames_in_flight_keep_frame_order(scene2):
-    """rtx_render(pixels = NULL) only queues the frame; up to three frames overlap on the device, each on its own
+    """rtx_render(pixels = NULL) only queues the frame; several frames overlap on the device, each on its own
     stream with its own path state, while the running mean still takes them in order (k_resolve launches are
     chained by events). The result must be the serial one, bit for bit, and the oracle's."""
     d, cam = scene2.desc(), scene2.camera
     frames = (0, 1, 2, 3, 4, 5, 6, 0, 1, 2, 3)          # includes a restart of the mean (frameCounter = 0)
     out = {}
-    for fif in (1, 3):
+    for fif in (1, 3, 14):                              # 14: more streams than hardware queues, more contexts than frames
         r = HIPShader(scene2, frames_in_flight=fif)
         for fc in frames:
             r.frame_counter = fc
@@ -317,6 +317,7 @@ def test_frames_in_flight_keep_frame_order(scene2):
         out[(fif, "sync")] = px
         r.close()
     assert (out[1] == out[3]).all() and (out[(1, "sync")] == out[(3, "sync")]).all()
+    assert (out[1] == out[14]).all() and (out[(1, "sync")] == out[(14, "sync")]).all()
     want = np.zeros_like(out[1])
     for fc in frames:
         oracle.render(d, cam, fc, want, 8)
