@@ -93,6 +93,12 @@ struct RtxRenderer {
     uint64_t frameSeq = 0;
     uint64_t primaryRays = 0;            // rays of bounce 0 since the last reset (known on the host)
 
+    // Frame batches: a rank that owns 1/N of the tiles has queues 1/N as long, and short launches are mostly
+    // tail. Frames queued with pixels == NULL are therefore collected and up to `batch` of them rendered by one
+    // set of launches (DevBatch); every entry point that needs results flushes the collection first.
+    int batch = 1;
+    std::vector<std::pair<RtxCamera, uint32_t>> queued;
+
     // timing
     hipEvent_t ev[kRing][kEvents];
     bool pending[kRing] = {};
@@ -419,11 +425,6 @@ void set_grids(RtxRenderer* r, uint32_t expected) {
     r->launchShade = (int)std::max<uint64_t>((uint64_t)std::min(r->numCUs / 2, r->gridShade), std::min<uint64_t>((uint64_t)r->gridShade, (e + perShadeBlock - 1) / perShadeBlock));
 }
 
-// every frame in flight finished (the host-side entry points that touch the framebuffer start here)
-int sync_all(RtxRenderer* r) {
-    for (auto& c : r->ctx) if (c.stream) HIP_TRY(hipStreamSynchronize(c.stream));
-    return 0;
-}
 
 void finish_timing(RtxRenderer* r, int slot) {
     if (!r->pending[slot]) return;
@@ -450,12 +451,12 @@ void finish_timing(RtxRenderer* r, int slot) {
 void dispatch_trace(RtxRenderer* r, const float4* o, const float4* d, int countIdx, int workIdx, uint32_t fixedCount);
 
 template <int MODE>
-void launch_primary(RtxRenderer* r, const DevFrame& fr, int workIdx) {
+void launch_primary(RtxRenderer* r, const DevBatch& bt, int workIdx) {
     if (r->cfg.countStats)
-        hipLaunchKernelGGL((k_primary<MODE, true>), dim3(r->launchTrace), dim3(RTX_BLOCK), r->ldsTrace, r->stream, r->sc, fr, r->dTiles,
+        hipLaunchKernelGGL((k_primary<MODE, true>), dim3(r->launchTrace), dim3(RTX_BLOCK), r->ldsTrace, r->stream, r->sc, bt, r->dTiles,
                            r->dRqO[0], r->dRqD[0], r->dHitT, r->dHitLeaf, r->dSeeds, r->dCtrl, r->dStats, workIdx);
     else
-        hipLaunchKernelGGL((k_primary<MODE, false>), dim3(r->launchTrace), dim3(RTX_BLOCK), r->ldsTrace, r->stream, r->sc, fr, r->dTiles,
+        hipLaunchKernelGGL((k_primary<MODE, false>), dim3(r->launchTrace), dim3(RTX_BLOCK), r->ldsTrace, r->stream, r->sc, bt, r->dTiles,
                            r->dRqO[0], r->dRqD[0], r->dHitT, r->dHitLeaf, r->dSeeds, r->dCtrl, r->dStats, workIdx);
 }
 template <int MODE>
@@ -467,22 +468,14 @@ void launch_trace(RtxRenderer* r, const float4* o, const float4* d, int countIdx
         hipLaunchKernelGGL((k_trace<MODE, false>), dim3(r->launchTrace), dim3(RTX_BLOCK), r->ldsTrace, r->stream, r->sc, o, d,
                            r->dHitT, r->dHitLeaf, r->dCtrl, r->dStats, fixedCount, countIdx, workIdx);
 }
-void dispatch_primary(RtxRenderer* r, const DevFrame& fr, int workIdx) {
+void dispatch_primary(RtxRenderer* r, const DevBatch& bt, int workIdx) {
     // Bounce 0 is coherent (one 8x8 pixel block per wave): it keeps one ray per lane per batch, fused with
-    // ray generation. Measured at 4K / 10 M triangles: fused 2.48 ms, k_raygen + k_trace 2.47 ms,
-    // k_raygen + the lane-refill kernel 3.7 ms (refill mixes rays of different blocks in a wave).
-    if (r->mode == RTX_MODE_CULLED && getenv("RTX_SPLIT_PRIMARY")) {      // experiment switch
-        if (r->numSlots == 0) return;
-        hipLaunchKernelGGL(k_raygen, dim3((r->numSlots + RTX_BLOCK - 1) / RTX_BLOCK), dim3(RTX_BLOCK), 0, r->stream, fr, r->dTiles,
-                           r->dRqO[0], r->dRqD[0], r->dHitLeaf, r->dSeeds);
-        if (atoi(getenv("RTX_SPLIT_PRIMARY")) == 2) launch_trace<RTX_MODE_CULLED>(r, r->dRqO[0], r->dRqD[0], 0, workIdx, r->numSlots);
-        else dispatch_trace(r, r->dRqO[0], r->dRqD[0], 0, workIdx, r->numSlots);
-        return;
-    }
-    if (r->mode == RTX_MODE_LINEAR) launch_primary<RTX_MODE_LINEAR>(r, fr, workIdx);
-    else if (r->mode == RTX_MODE_EXACT) launch_primary<RTX_MODE_EXACT>(r, fr, workIdx);
-    else if (r->mode == RTX_MODE_CULLED_BIG) launch_primary<RTX_MODE_CULLED_BIG>(r, fr, workIdx);
-    else launch_primary<RTX_MODE_CULLED>(r, fr, workIdx);
+    // ray generation. Measured at 4K / 10 M triangles: fused 2.48 ms, ray generation + k_trace 2.47 ms,
+    // ray generation + the lane-refill kernel 3.7 ms (refill mixes rays of different blocks in a wave).
+    if (r->mode == RTX_MODE_LINEAR) launch_primary<RTX_MODE_LINEAR>(r, bt, workIdx);
+    else if (r->mode == RTX_MODE_EXACT) launch_primary<RTX_MODE_EXACT>(r, bt, workIdx);
+    else if (r->mode == RTX_MODE_CULLED_BIG) launch_primary<RTX_MODE_CULLED_BIG>(r, bt, workIdx);
+    else launch_primary<RTX_MODE_CULLED>(r, bt, workIdx);
 }
 // fixedCount: queue length when it is known on the host (bounce 0 / probes), else read from ctrl[countIdx]
 void dispatch_trace(RtxRenderer* r, const float4* o, const float4* d, int countIdx, int workIdx, uint32_t fixedCount) {
@@ -658,7 +651,15 @@ int rtx_create(const RtxSceneDesc* scene, const RtxConfig* cfgIn, RtxRenderer** 
 
     // per-path state (indexed by slot) and queues (indexed by queue position; the bounce queues hold
     // up to one unfinished run of holes per shade wave on top of the live rays)
-    const size_t n = std::max<size_t>(r->numSlots, 64);
+    // frames per batch: as many as make this rank's queues about as long as a whole frame's (1 on a single rank)
+    {
+        const uint64_t allSlots = (uint64_t)r->tilesX * r->tilesY * r->tileW * r->tileH;
+        uint64_t want = r->numSlots ? allSlots / r->numSlots : 1;
+        if (const char* e = getenv("RTX_BATCH")) want = (uint64_t)std::max(1, atoi(e));
+        while (want > 1 && (uint64_t)r->numSlots * want > 0x7fffff00ull) --want;
+        r->batch = (int)std::max<uint64_t>(1, std::min<uint64_t>(RTX_MAX_BATCH, want));
+    }
+    const size_t n = std::max<size_t>((size_t)r->numSlots * r->batch, 64);
     const size_t nq = n + (size_t)r->gridShade * (RTX_BLOCK / 64) * RTX_MAX_RUN;
     CREATE_HIP(hipMalloc((void**)&r->dStats, RTX_STAT_WORDS * sizeof(unsigned long long)));
     CREATE_HIP(hipMemset(r->dStats, 0, RTX_STAT_WORDS * sizeof(unsigned long long)));
@@ -706,29 +707,33 @@ int rtx_create(const RtxSceneDesc* scene, const RtxConfig* cfgIn, RtxRenderer** 
         }
     }
     activate(r, 0);
-    for (int b = 0; b < 4; ++b) r->queueHint[b] = r->numSlots;
-    set_grids(r, r->numSlots);
+    for (int b = 0; b < 4; ++b) r->queueHint[b] = r->numSlots * (uint32_t)r->batch;
+    set_grids(r, r->numSlots * (uint32_t)r->batch);
     CREATE_HIP(hipDeviceSynchronize());
     createClock.lap("rtx_create total");
     if (getenv("RTX_VERBOSE"))
         fprintf(stderr, "[rtx] %d leaves, reference tree depth %d, own tree %s depth %d, stack %d entries, LDS %zu B/block, %d blocks/CU x %d CUs, mode %d\n",
                 r->sc.numLeaves, flat.maxDepth, flat.fast.empty() ? "absent" : "built", flat.fastDepth, r->sc.stackDepth, r->ldsTrace,
                 blocksPerCU, r->numCUs, r->mode),
-        fprintf(stderr, "[rtx] %d frames in flight (%d hardware queues), shade grid %d blocks (%d per CU), queue capacity %zu entries for %zu slots, %zu wide nodes (%.2f per leaf)\n",
-                depth, hwQueues, r->gridShade, shadeBlocksPerCU, nq, n, flat.fast.size(), r->sc.numLeaves ? (double)flat.fast.size() / r->sc.numLeaves : 0.0);
+        fprintf(stderr, "[rtx] %d frames per batch, %d batches in flight (%d hardware queues), shade grid %d blocks (%d per CU), queue capacity %zu entries for %zu slots, %zu wide nodes (%.2f per leaf)\n",
+                r->batch, depth, hwQueues, r->gridShade, shadeBlocksPerCU, nq, n, flat.fast.size(), r->sc.numLeaves ? (double)flat.fast.size() / r->sc.numLeaves : 0.0);
     *out = r;
     return 0;
 }
 
-static int render_frame(RtxRenderer* r, const RtxCamera* cam, uint32_t fc, bool primaryOnly) {
+// One set of launches for `count` frames (1 <= count <= r->batch), in call order.
+static int render_batch(RtxRenderer* r, const std::pair<RtxCamera, uint32_t>* frames, int count, bool primaryOnly) {
     HIP_TRY(hipSetDevice(r->device));
-    // frames take the contexts in turn; a context's stream orders a frame after the one that used it last
+    // batches take the contexts in turn; a context's stream orders a batch after the one that used it last
     activate(r, (int)(r->frameSeq++ % r->ctx.size()));
     const int slot = r->ringPos;
     r->ringPos = (r->ringPos + 1) % kRing;
-    finish_timing(r, (slot + kRing - kLag) % kRing);     // the frame queued kLag frames ago has long finished
-    const DevFrame fr = make_frame(r, cam, fc);
-    {   // queue lengths of this context's previous frame, if they have arrived
+    finish_timing(r, (slot + kRing - kLag) % kRing);     // the batch queued kLag batches ago has long finished
+    DevBatch bt{};
+    bt.count = count;
+    for (int i = 0; i < RTX_MAX_BATCH; ++i) bt.fr[i] = make_frame(r, &frames[std::min(i, count - 1)].first, frames[std::min(i, count - 1)].second);
+    const uint32_t slots = r->numSlots * (uint32_t)count;
+    {   // queue lengths of this context's previous batch, if they have arrived
         RtxRenderer::FrameCtx& c = r->ctx[r->active];
         if (c.countsPending && hipEventQuery(c.countsReady) == hipSuccess) {
             for (int b = 1; b < 4; ++b) r->queueHint[b] = c.hCounts[b];
@@ -738,34 +743,34 @@ static int render_frame(RtxRenderer* r, const RtxCamera* cam, uint32_t fc, bool 
     HIP_TRY(hipMemsetAsync(r->dCtrl, 0, RTX_CTRL_WORDS * sizeof(uint32_t), r->stream));
     hipEvent_t* ev = r->ev[slot];
     HIP_TRY(hipEventRecord(ev[0], r->stream));
-    set_grids(r, r->numSlots);
-    dispatch_primary(r, fr, 0);
+    set_grids(r, slots);
+    dispatch_primary(r, bt, 0);
     HIP_TRY(hipEventRecord(ev[1], r->stream));
     if (!primaryOnly) {
         int in = 0;
         for (int b = 0; b < 4; ++b) {
             if (b > 0) {
-                set_grids(r, std::min(r->queueHint[b], r->queueHint[b - 1]));
+                set_grids(r, std::min(slots, std::min(r->queueHint[b], r->queueHint[b - 1])));
                 dispatch_trace(r, r->dRqO[in], r->dRqD[in], b, 2 * b, 0);
                 HIP_TRY(hipEventRecord(ev[2 * b + 1], r->stream));
             }
-            hipLaunchKernelGGL(k_shade, dim3(r->launchShade), dim3(RTX_BLOCK), 0, r->stream, r->sc, fr, r->dTiles, b, r->linear ? 1 : 0,
+            hipLaunchKernelGGL(k_shade, dim3(r->launchShade), dim3(RTX_BLOCK), 0, r->stream, r->sc, bt, r->dTiles, b, r->linear ? 1 : 0,
                                r->dRqO[in], r->dRqD[in], r->dHitT, r->dHitLeaf, r->dRqO[in ^ 1], r->dRqD[in ^ 1],
                                r->dLight, r->dAcc, r->dSeeds, r->dCtrl, r->dStats, 2 * b + 1);
             HIP_TRY(hipEventRecord(ev[2 * b + 2], r->stream));
             in ^= 1;
         }
-        // the running mean takes the frames in order: this frame's resolve waits for the previous frame's
+        // the running mean takes the frames in order: this batch's resolve waits for the previous batch's
         if (r->lastResolved >= 0 && r->lastResolved != r->active)
             HIP_TRY(hipStreamWaitEvent(r->stream, r->ctx[r->lastResolved].resolved, 0));
         if (r->numSlots)
-            hipLaunchKernelGGL(k_resolve, dim3((r->numSlots + RTX_BLOCK - 1) / RTX_BLOCK), dim3(RTX_BLOCK), 0, r->stream, fr, r->dTiles,
+            hipLaunchKernelGGL(k_resolve, dim3((r->numSlots + RTX_BLOCK - 1) / RTX_BLOCK), dim3(RTX_BLOCK), 0, r->stream, bt, r->dTiles,
                                r->dAcc, r->dFb);
         HIP_TRY(hipEventRecord(r->ctx[r->active].resolved, r->stream));
         r->lastResolved = r->active;
         {
             RtxRenderer::FrameCtx& c = r->ctx[r->active];
-            if (!c.countsPending) {
+            if (!c.countsPending && count == r->batch) {       // hints describe full batches
                 HIP_TRY(hipMemcpyAsync(c.hCounts, r->dCtrl, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, r->stream));
                 HIP_TRY(hipEventRecord(c.countsReady, r->stream));
                 c.countsPending = true;
@@ -773,11 +778,32 @@ static int render_frame(RtxRenderer* r, const RtxCamera* cam, uint32_t fc, bool 
         }
         HIP_TRY(hipEventRecord(ev[kEvents - 1], r->stream));
         r->pending[slot] = true;
-        r->totals.frames++;
-        r->primaryRays += r->localPixels;
+        r->totals.frames += (uint64_t)count;
+        r->primaryRays += r->localPixels * (uint64_t)count;
     }
     HIP_TRY(hipGetLastError());
     return 0;
+}
+
+// renders whatever rtx_render(pixels = NULL) has collected
+static int flush_queued(RtxRenderer* r) {
+    if (r->queued.empty()) return 0;
+    std::vector<std::pair<RtxCamera, uint32_t>> q;
+    q.swap(r->queued);
+    return render_batch(r, q.data(), (int)q.size(), false);
+}
+
+// every frame queued or in flight finished (the host-side entry points that touch the framebuffer start here)
+static int sync_all(RtxRenderer* r) {
+    if (flush_queued(r)) return 1;
+    for (auto& c : r->ctx) if (c.stream) HIP_TRY(hipStreamSynchronize(c.stream));
+    return 0;
+}
+
+static int render_frame(RtxRenderer* r, const RtxCamera* cam, uint32_t fc, bool primaryOnly) {
+    if (flush_queued(r)) return 1;
+    const std::pair<RtxCamera, uint32_t> one(*cam, fc);
+    return render_batch(r, &one, 1, primaryOnly);
 }
 
 // device framebuffer -> host array
@@ -840,6 +866,12 @@ static int copy_out(RtxRenderer* r, float* pixels) {
 int rtx_render(RtxRenderer* r, const RtxCamera* camera, uint32_t frameCounter, float* pixels_rgba) {
     if (!r) return fail("renderer is NULL");
     if (check_camera(camera)) return 1;
+    if (!pixels_rgba && r->batch > 1) {
+        // nothing has to be delivered yet: collect the frame; a full batch is rendered by one set of launches
+        r->queued.emplace_back(*camera, frameCounter);
+        if ((int)r->queued.size() >= r->batch) return flush_queued(r);
+        return 0;
+    }
     if (render_frame(r, camera, frameCounter, false)) return 1;
     if (pixels_rgba) return copy_out(r, pixels_rgba);
     return 0;

@@ -91,3 +91,13 @@ struct DevFrame {
     int numLocalTiles;
     int numSlots;       // numLocalTiles * tileW * tileH
 };
+
+// Frames that share one set of launches (rtx_api.hip "frame batches"): a rank that owns 1/N of the tiles
+// renders up to RTX_MAX_BATCH queued frames together, so its ray queues are as long as a whole frame's.
+// Batch slot s = (tile * count + frame) * tilePixels + pixel-in-tile: the frames of one tile are neighbours,
+// so a queue segment is still an image region (and the same few nodes serve all of a tile's frames).
+#define RTX_MAX_BATCH 8
+struct DevBatch {
+    DevFrame fr[RTX_MAX_BATCH];
+    int count;
+};

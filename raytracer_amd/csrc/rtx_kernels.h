@@ -161,28 +161,6 @@ __device__ __forceinline__ void primary_ray(const DevFrame& fr, int x, int y, ui
     d = normalize4(sub4(p, o));
 }
 
-// Culled mode: ray generation is its own launch (it needs ~100 VGPRs for the double-precision
-// jitter arithmetic; the traversal kernel then keeps 8 waves per SIMD) and writes the bounce-0 queue
-// in slot order. rqD.w = 1 marks a slot outside the image.
-__global__ __launch_bounds__(RTX_BLOCK) void k_raygen(DevFrame fr, const int2* __restrict__ tiles,
-                                                      float4* __restrict__ rqO, float4* __restrict__ rqD,
-                                                      int* __restrict__ hitLeaf, uint32_t* __restrict__ seeds) {
-    const uint32_t slot = blockIdx.x * RTX_BLOCK + threadIdx.x;
-    if (slot >= (uint32_t)fr.numSlots) return;
-    int x, y;
-    if (slot_to_pixel(fr, tiles, slot, x, y)) {
-        uint32_t seed; F4 o, d;
-        primary_ray(fr, x, y, seed, o, d);
-        rqO[slot] = make_float4(o.x, o.y, o.z, __int_as_float((int)slot));
-        rqD[slot] = make_float4(d.x, d.y, d.z, 0.0f);
-        seeds[slot] = seed;
-    } else {
-        rqO[slot] = make_float4(0, 0, 0, __int_as_float((int)slot));
-        rqD[slot] = make_float4(0, 0, 0, 1.0f);
-        hitLeaf[slot] = RTX_INVALID_SLOT;
-    }
-}
-
 #ifndef RTX_PRIMARY_GUIDE
 #define RTX_PRIMARY_GUIDE 0
 #endif
@@ -190,7 +168,7 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_raygen(DevFrame fr, const int2* _
 // VGPRs for the whole kernel and leave 4 waves; capped at 96 it spills 13 dwords outside the traversal loop
 // and the launch runs 9 % faster.
 template <int MODE, bool COUNT>
-__global__ __launch_bounds__(RTX_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_primary(DevScene sc, DevFrame fr, const int2* __restrict__ tiles,
+__global__ __launch_bounds__(RTX_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_primary(DevScene sc, DevBatch bt, const int2* __restrict__ tiles,
                                                        float4* __restrict__ rqO, float4* __restrict__ rqD,
                                                        float* __restrict__ hitT, int* __restrict__ hitLeaf,
                                                        uint32_t* __restrict__ seeds, uint32_t* __restrict__ ctrl,
@@ -198,13 +176,22 @@ __global__ __launch_bounds__(RTX_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 5)
     int* stack = rtx_lds + threadIdx.x;
     uint32_t ic = 0, lc = 0;
     const int countIdx = 0;
-    WorkIter<RTX_PRIMARY_GUIDE, true> work((uint32_t)fr.numSlots);
+    const uint32_t nf = (uint32_t)bt.count, tilePix = (uint32_t)(bt.fr[0].tileW * bt.fr[0].tileH);
+    WorkIter<RTX_PRIMARY_GUIDE, true> work((uint32_t)bt.fr[0].numSlots * nf);
     for (;;) {
         const uint32_t base = work.next(ctrl, workIdx);
         if (base == 0xffffffffu) break;
         const uint32_t slot = base + (threadIdx.x & 63u);
+        // batch slot -> (frame, slot inside the frame); a wave's 64 slots lie inside one tile of one frame
+        uint32_t f = 0, p = slot;
+        if (nf > 1) {
+            const uint32_t tb = base / tilePix;
+            f = tb % nf;
+            p = (tb / nf) * tilePix + (slot - tb * tilePix);
+        }
+        const DevFrame& fr = bt.fr[f];
         int x, y;
-        if (slot_to_pixel(fr, tiles, slot, x, y)) {
+        if (slot_to_pixel(fr, tiles, p, x, y)) {
             uint32_t seed; F4 o, d;
             primary_ray(fr, x, y, seed, o, d);
             Hit h = closest_hit<MODE, COUNT>(sc, o.x, o.y, o.z, d.x, d.y, d.z, stack, ic, lc);
@@ -421,7 +408,7 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_trace_slow(DevScene sc, const flo
 }
 
 // src/ThreadedShader.cpp:155-180 for bounce `bounce` of every queued path.
-__global__ __launch_bounds__(RTX_BLOCK) void k_shade(DevScene sc, DevFrame fr, const int2* __restrict__ tiles, int bounce, int linearMode,
+__global__ __launch_bounds__(RTX_BLOCK) void k_shade(DevScene sc, DevBatch bt, const int2* __restrict__ tiles, int bounce, int linearMode,
                                                      const float4* __restrict__ rqOin, const float4* __restrict__ rqDin,
                                                      const float* __restrict__ hitT, const int* __restrict__ hitLeaf,
                                                      float4* __restrict__ rqOout, float4* __restrict__ rqDout,
@@ -429,8 +416,8 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_shade(DevScene sc, DevFrame fr, c
                                                      uint32_t* __restrict__ seeds,
                                                      uint32_t* __restrict__ ctrl, unsigned long long* __restrict__ stats, int workIdx) {
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t count = bounce == 0 ? (uint32_t)fr.numSlots : ctrl[RTX_CTRL_COUNT(bounce)];
-    const F4 camPos = mk4(fr.pos[0], fr.pos[1], fr.pos[2]);
+    const uint32_t nf = (uint32_t)bt.count, tilePix = (uint32_t)(bt.fr[0].tileW * bt.fr[0].tileH);
+    const uint32_t count = bounce == 0 ? (uint32_t)bt.fr[0].numSlots * nf : ctrl[RTX_CTRL_COUNT(bounce)];
     uint32_t hits = 0;
     // Survivors go to the next queue in wave-private runs: one device atomic reserves `run` entries,
     // the wave fills them densely across iterations, and what is left of its last run when the kernel
@@ -467,6 +454,8 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_shade(DevScene sc, DevFrame fr, c
                 F4 dirForPoint = linearMode ? mul4(d, 1.0000001f) : d;   // src/ThreadedShader.cpp:217,232
                 F4 point = add4(o, mul4(dirForPoint, t));
                 F4 normal = hit_normal(prim, point);
+                const uint32_t f = nf > 1 ? ((uint32_t)slot / tilePix) % nf : 0u;      // the path's frame: its camera
+                const F4 camPos = mk4(bt.fr[f].pos[0], bt.fr[f].pos[1], bt.fr[f].pos[2]);
                 F4 color = compute_color(sc, camPos, o, d, point, normal, prim, light, seed);
                 light = clamp01_sse(light);
                 acc = clamp01_sse(add4(acc, color));
@@ -511,15 +500,19 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_shade(DevScene sc, DevFrame fr, c
 // frame (src/ThreadedShader.cpp:179-180). A launch of its own because frames are pipelined (several in flight
 // on separate streams) while the running mean has to take them in order: the resolve launches
 // are chained by events, everything before them overlaps freely.
-__global__ __launch_bounds__(RTX_BLOCK) void k_resolve(DevFrame fr, const int2* __restrict__ tiles, const float4* __restrict__ accArr,
+__global__ __launch_bounds__(RTX_BLOCK) void k_resolve(DevBatch bt, const int2* __restrict__ tiles, const float4* __restrict__ accArr,
                                                        float4* __restrict__ fb) {
-    const uint32_t slot = blockIdx.x * RTX_BLOCK + threadIdx.x;
-    if (slot >= (uint32_t)fr.numSlots) return;
+    const DevFrame& fr0 = bt.fr[0];
+    const uint32_t p = blockIdx.x * RTX_BLOCK + threadIdx.x;
+    if (p >= (uint32_t)fr0.numSlots) return;
     int x, y;
-    if (!slot_to_pixel(fr, tiles, slot, x, y)) return;
-    const size_t pix = (size_t)y * (size_t)fr.width + (size_t)x;
-    const F4 prev = from4(fb[pix]);
-    const F4 res = lerp_color(prev, from4(accArr[slot]), fr.lerpScale);
+    if (!slot_to_pixel(fr0, tiles, p, x, y)) return;
+    const size_t pix = (size_t)y * (size_t)fr0.width + (size_t)x;
+    const uint32_t nf = (uint32_t)bt.count, tilePix = (uint32_t)(fr0.tileW * fr0.tileH);
+    const uint32_t tile = p / tilePix, within = p - tile * tilePix;
+    F4 res = from4(fb[pix]);
+    for (uint32_t f = 0; f < nf; ++f)       // the frames of a batch in call order
+        res = lerp_color(res, from4(accArr[(size_t)(tile * nf + f) * tilePix + within]), bt.fr[f].lerpScale);
     fb[pix] = make_float4(res.x, res.y, res.z, res.w);
 }
 

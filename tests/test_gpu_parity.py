@@ -322,3 +322,38 @@ def test_frames_in_flight_keep_frame_order(scene2):
     for fc in frames:
         oracle.render(d, cam, fc, want, 8)
     check_fb(out[3], want)
+
+
+def test_frame_batches_render_the_serial_frames(scene2, synth_small, monkeypatch):
+    """A rank that owns 1/N of the tiles collects frames queued with pixels = NULL and renders up to N (at most
+    8) of them with one set of launches (DevBatch). The frames still enter the running mean in call order, each with
+    its own camera and frameCounter: the image must be the one the frame-by-frame path produces, bit for bit —
+    with full batches, a partial batch at the end, a restart of the mean and a camera change inside a batch."""
+    from raytracer_amd.scene import orbit
+    for scene, world, rank, forced in ((scene2, 4, 1, None), (synth_small, 8, 3, None), (scene2, 1, 0, "3")):
+        d = scene.desc()
+        frames = (0, 1, 2, 3, 4, 0, 1, 2, 3, 4, 5)           # 11 frames: partial last batch whatever the batch size
+        out = {}
+        for batch in ("1", forced):
+            if batch is None:
+                monkeypatch.delenv("RTX_BATCH", raising=False)
+            else:
+                monkeypatch.setenv("RTX_BATCH", batch)
+            r = HIPShader(scene, rank=rank, world_size=world, frames_in_flight=3)
+            cam = type(scene.camera).from_buffer_copy(scene.camera)
+            for i, fc in enumerate(frames):
+                if i == 6:
+                    orbit(cam, 20.0, 5.0)                       # a different camera from the 7th frame on
+                r.frame_counter = fc
+                r.Render(None, cam)
+            c = r.counters()
+            assert c.frames == len(frames) and c.raysPerBounce[0] == len(frames) * r.local_pixel_count()
+            out[batch] = r.download()
+            # a synchronous call right after queued ones
+            r.frame_counter = 6; r.Render(None, cam)
+            px = np.zeros((d.height, d.width, 4), np.float32)
+            r.frame_counter = 7; r.Render(px, cam)
+            out[(batch, "sync")] = px
+            r.close()
+        assert (out["1"] == out[forced]).all() and (out[("1", "sync")] == out[(forced, "sync")]).all()
+    monkeypatch.delenv("RTX_BATCH", raising=False)
