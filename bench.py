@@ -278,7 +278,7 @@ def main():
                "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": args.workload, "triangles": ntri, "resolution": [W, H], "bounces": 4,
                           "spp_per_step": 1, "traversal": args.traversal, "partition": f"tiles64x32 round-robin x{world}",
-                          "camera": "orbit" if args.orbit else "fixed", "collective": backend if use_dist else None, "frames_in_flight": args.frames_in_flight or 14, "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES")},
+                          "camera": "orbit" if args.orbit else "fixed", "collective": backend if use_dist else None, "frames_in_flight": args.frames_in_flight or 14, "frames_per_batch": int(os.environ.get("RTX_BATCH", min(world, 8))), "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES")},
                "roofline": roofline, "cpu_baseline": cpu, "extra": extra}
         print(json.dumps(out), flush=True)
     if use_dist:
