@@ -122,6 +122,7 @@ struct Flat {
     int rootRef = 0, fastRoot = 0;
     int maxDepth = 0, fastDepth = 0;
     bool nested = true;                 // every box contains its children (precondition of the own tree)
+    double sliverFraction = 0.0;        // triangles with longest edge^2 / (2 area) > 32 (or no area at all)
 };
 
 inline float i2f(int32_t v) { float f; memcpy(&f, &v, 4); return f; }
@@ -206,6 +207,28 @@ int flatten(const RtxSceneDesc& s, bool useBVH, bool wantFast, int nthreads, Fla
         }
     });
     if (err.any()) return fail(err.msg);
+    {   // shape statistics for the culling slack (rtx_traverse.h)
+        std::atomic<uint64_t> tris{0}, slivers{0};
+        parallel_for(nObj, nthreads, [&](uint64_t b, uint64_t e) {
+            uint64_t t = 0, sl = 0;
+            for (uint64_t i = b; i < e; ++i) {
+                const RtxObject& o = s.objects[i];
+                if (o.type != RTX_TRIANGLE) continue;
+                const RtxVec4 &A = o.vertices[0], &B = o.vertices[1], &C = o.vertices[2];
+                const double e1[3] = {(double)B.x - A.x, (double)B.y - A.y, (double)B.z - A.z};
+                const double e2[3] = {(double)C.x - A.x, (double)C.y - A.y, (double)C.z - A.z};
+                const double e3[3] = {(double)C.x - B.x, (double)C.y - B.y, (double)C.z - B.z};
+                const double n[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+                const double area2 = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);       // 2 x area
+                const double l2 = std::max({e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2], e2[0] * e2[0] + e2[1] * e2[1] + e2[2] * e2[2],
+                                            e3[0] * e3[0] + e3[1] * e3[1] + e3[2] * e3[2]});
+                ++t;
+                if (!(l2 <= 32.0 * area2)) ++sl;          // also NaN / zero area
+            }
+            tris += t; slivers += sl;
+        });
+        f.sliverFraction = tris ? (double)slivers / (double)tris : 0.0;
+    }
     if (!useBVH) {
         f.leaf.resize(nObj * 4); f.shade.resize(nObj * 8);
         parallel_for(nObj, nthreads, [&](uint64_t b, uint64_t e) {
@@ -633,6 +656,8 @@ int rtx_create(const RtxSceneDesc* scene, const RtxConfig* cfgIn, RtxRenderer** 
     r->sc.rootRef = flat.rootRef;
     r->sc.fast = r->dFast;            // 4-wide nodes, 8 float4 each (NULL unless the mode is CULLED / CULLED_BIG)
     r->sc.fastRoot = flat.fastRoot;
+    r->sc.cullSlack = flat.sliverFraction > 1e-3 ? INFINITY : RTX_CULL_SLACK_DEFAULT;
+    if (const char* e = getenv("RTX_CULL_SLACK")) r->sc.cullSlack = (float)atof(e);      // experiments ("inf" disables culling)
     r->sc.numLeaves = (int)(flat.leaf.size() / 4);
     r->sc.numInner = (int)(flat.inner.size() / 4);
     r->sc.numMaterials = (int)scene->numMaterials;
@@ -712,8 +737,8 @@ int rtx_create(const RtxSceneDesc* scene, const RtxConfig* cfgIn, RtxRenderer** 
     CREATE_HIP(hipDeviceSynchronize());
     createClock.lap("rtx_create total");
     if (getenv("RTX_VERBOSE"))
-        fprintf(stderr, "[rtx] %d leaves, reference tree depth %d, own tree %s depth %d, stack %d entries, LDS %zu B/block, %d blocks/CU x %d CUs, mode %d\n",
-                r->sc.numLeaves, flat.maxDepth, flat.fast.empty() ? "absent" : "built", flat.fastDepth, r->sc.stackDepth, r->ldsTrace,
+        fprintf(stderr, "[rtx] culling slack %g (%.3f %% slivers), %d leaves, reference tree depth %d, own tree %s depth %d, stack %d entries, LDS %zu B/block, %d blocks/CU x %d CUs, mode %d\n",
+                (double)r->sc.cullSlack, 100.0 * flat.sliverFraction, r->sc.numLeaves, flat.maxDepth, flat.fast.empty() ? "absent" : "built", flat.fastDepth, r->sc.stackDepth, r->ldsTrace,
                 blocksPerCU, r->numCUs, r->mode),
         fprintf(stderr, "[rtx] %d frames per batch, %d batches in flight (%d hardware queues), shade grid %d blocks (%d per CU), queue capacity %zu entries for %zu slots, %zu wide nodes (%.2f per leaf)\n",
                 r->batch, depth, hwQueues, r->gridShade, shadeBlocksPerCU, nq, n, flat.fast.size(), r->sc.numLeaves ? (double)flat.fast.size() / r->sc.numLeaves : 0.0);

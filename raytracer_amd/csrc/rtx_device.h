@@ -77,6 +77,7 @@ struct DevScene {
     int useBVH;
     int stackDepth;     // stack entries a lane can need (tree depth + 2)
     int2* spill;        // [stackDepth][threads of the trace grid]: stack entries below the LDS window
+    float cullSlack;    // relative slack of distance culling (rtx_traverse.h); +inf = never cull
 };
 
 struct DevFrame {

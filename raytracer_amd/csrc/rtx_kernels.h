@@ -353,7 +353,7 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_trace_refill(DevScene sc, const f
                     if (COUNT) lc++;
                     if (t > 0.01f && (t < best.t || (t == best.t && best.leaf >= 0 && box > best.box))) {
                         best.t = t; best.leaf = leafIdx; best.box = box;
-                        limit = t + t * RTX_CULL_SLACK;
+                        limit = t + t * sc.cullSlack;
                     }
                     cur = RTX_NEED_POP;
                 }
