@@ -123,7 +123,8 @@ typedef struct RtxSceneDesc {
     int32_t  _pad;
 } RtxSceneDesc;
 
-enum { RTX_TRAVERSE_CULLED = 0,   /* near-first, distance-culled; same closest hit + tie-break  */
+enum { RTX_TRAVERSE_CULLED = 0,   /* near-first, distance-culled with a per-scene slack (none on sliver geometry): same closest hit + tie-break
+                                     except when a grazing triangle's computed t undercuts its own box by more than the slack */
        RTX_TRAVERSE_EXACT  = 1 }; /* reference visit set: no distance culling at all            */
 
 typedef struct RtxConfig {
