@@ -1,7 +1,7 @@
 // rtx_run — headless driver for the HIP backend with the reference's flags
 // (src/Configurator.cpp:78-142): -L <scn> -w <px> -h <px> -B -F <frames> -O,
 // plus -o <file.pfm|file.bmp> to write the frame (the reference's -F mode never
-// writes one, src/Main.cpp:46-54) and -N <triangles> for the synthetic scene.
+// writes one, src/Main.cpp:46-54), -g <gamma> for the BMP, and -N <triangles> for the synthetic scene.
 // It replays src/Main.cpp:13-54 (bounded frames) and :56-82 (orbit camera, run
 // headlessly for -F frames) with HIPShader in the place of ThreadedShader.
 // Per-frame timing goes to Performance_log.csv in the reference's format
@@ -28,7 +28,9 @@ static void write_pfm(const char* path, const std::vector<Color>& px, uint32_t w
     fclose(f);
 }
 
-static void write_bmp(const char* path, const std::vector<Color>& px, uint32_t w, uint32_t h) {
+// 24-bit BMP, bottom-up rows like the reference's y axis; gamma > 0 applies v^(1/gamma) first (the reference
+// carries gamma = 2.2 in its context, src/RenderingContext.h:48, but only the OpenCL display path uses it)
+static void write_bmp(const char* path, const std::vector<Color>& px, uint32_t w, uint32_t h, float gamma) {
     FILE* f = fopen(path, "wb");
     if (!f) { fprintf(stderr, "cannot write %s\n", path); return; }
     const uint32_t row = (w * 3 + 3) & ~3u, size = 54 + row * h;
@@ -41,7 +43,7 @@ static void write_bmp(const char* path, const std::vector<Color>& px, uint32_t w
     for (uint32_t y = 0; y < h; ++y) {
         for (uint32_t x = 0; x < w; ++x) {
             const Color& c = px[(size_t)y * w + x];
-            auto q = [](float v) { v = v < 0 ? 0 : (v > 1 ? 1 : v); return (unsigned char)(v * 255.0f + 0.5f); };
+            auto q = [gamma](float v) { v = v < 0 ? 0 : (v > 1 ? 1 : v); if (gamma > 0) v = powf(v, 1.0f / gamma); return (unsigned char)(v * 255.0f + 0.5f); };
             line[3 * x] = q(c.z); line[3 * x + 1] = q(c.y); line[3 * x + 2] = q(c.x);
         }
         fwrite(line.data(), 1, row, f);
@@ -51,7 +53,7 @@ static void write_bmp(const char* path, const std::vector<Color>& px, uint32_t w
 
 int main(int argc, char** argv) {
     const char* scenePath = nullptr; const char* outPath = nullptr;
-    int w = 1000, h = 1000, frames = 1; bool bvh = false, orbit = false; long long synth = 0;
+    int w = 1000, h = 1000, frames = 1; bool bvh = false, orbit = false; long long synth = 0; float gamma = 0.0f;
     for (int i = 1; i < argc; ++i) {
         const char* a = argv[i];
         if (a[0] != '-' || !a[1] || a[2]) { fprintf(stderr, "Unknown argument: %s\n", a); return -1; }
@@ -69,8 +71,9 @@ int main(int argc, char** argv) {
             case 'O': orbit = true; break;
             case 'o': outPath = val("an output file"); break;
             case 'N': synth = atoll(val("a triangle count")); break;
+            case 'g': gamma = (float)atof(val("a gamma value")); break;
             case 'V': case 'S': break;
-            case 'H': printf("Usage: rtx_run [-L scene.scn | -N triangles] [-w W] [-h H] [-B] [-F frames] [-O] [-o out.pfm|out.bmp]\n"); return 0;
+            case 'H': printf("Usage: rtx_run [-L scene.scn | -N triangles] [-w W] [-h H] [-B] [-F frames] [-O] [-o out.pfm|out.bmp] [-g gamma (BMP only, e.g. 2.2)]\n"); return 0;
             default: fprintf(stderr, "Unknown argument: %s\n", a); return -1;
         }
     }
@@ -125,7 +128,7 @@ int main(int argc, char** argv) {
            context.numBoundedFrames, total / frames * 1e3, c.totalMs / frames, c.rays / (c.totalMs * 1e-3) / 1e6);
     if (outPath) {
         const size_t n = strlen(outPath);
-        if (n > 4 && strcmp(outPath + n - 4, ".bmp") == 0) write_bmp(outPath, pixels, context.width, context.height);
+        if (n > 4 && strcmp(outPath + n - 4, ".bmp") == 0) write_bmp(outPath, pixels, context.width, context.height, gamma);
         else write_pfm(outPath, pixels, context.width, context.height);
     }
     delete service;

@@ -1,0 +1,41 @@
+"""The headless driver raytracer_amd/rtx_run: the reference's flags (src/Configurator.cpp:78-142) with HIPShader in
+the place of ThreadedShader (C++ mirror of the reference's render-service interface over the C ABI)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+RUN = os.path.join(os.path.dirname(HERE), "raytracer_amd", "rtx_run")
+
+
+def read_pfm(path):
+    with open(path, "rb") as f:
+        assert f.readline().strip() == b"PF"
+        w, h = (int(v) for v in f.readline().split())
+        assert float(f.readline()) < 0          # little endian
+        return np.frombuffer(f.read(), dtype="<f4").reshape(h, w, 3)
+
+
+def test_headless_driver_renders_and_logs(tmp_path):
+    if not os.path.exists(RUN):
+        pytest.fail("raytracer_amd/rtx_run is not built (python -c 'import __graft_entry__ as g; g.build()')")
+    out = subprocess.run([RUN, "-N", "3000", "-w", "200", "-h", "130", "-B", "-F", "3", "-o", "frame.pfm"],
+                         cwd=tmp_path, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    assert "Resolution : 192 x 128" in out.stdout          # rounded to multiples of 32 (src/Configurator.cpp:144-145)
+    img = read_pfm(tmp_path / "frame.pfm")
+    assert img.shape == (128, 192, 3) and np.isfinite(img).all() and img.max() <= 1.0 and img.min() >= 0.0 and img.std() > 0.01
+    log = (tmp_path / "Performance_log.csv").read_text().splitlines()
+    assert log[0] == "fps;frametime(ms)" and len(log) == 4   # src/PerformanceMonitor.cpp:10,27
+    # the same run through the BMP writer with display gamma
+    out = subprocess.run([RUN, "-N", "3000", "-w", "200", "-h", "130", "-B", "-F", "3", "-o", "frame.bmp", "-g", "2.2"],
+                         cwd=tmp_path, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    raw = (tmp_path / "frame.bmp").read_bytes()
+    assert raw[:2] == b"BM" and len(raw) == 54 + 192 * 3 * 128
+    bgr = np.frombuffer(raw[54:], dtype=np.uint8).reshape(128, 192, 3)
+    want = np.clip(img, 0, 1) ** (1 / 2.2) * 255.0 + 0.5
+    assert np.abs(bgr[:, :, ::-1].astype(np.float32) - np.floor(want)).max() <= 1.0
