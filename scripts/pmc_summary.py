@@ -24,7 +24,7 @@ class BounceNamer:
 
     def name(self, kernel):
         k = short(kernel)
-        if k.startswith("k_primary") or k.startswith("k_raygen"):
+        if k.startswith("k_primary"):
             self.trace, self.shade = 0, 0
             return k
         if k.startswith("k_trace_refill"):
