@@ -48,7 +48,7 @@ def main():
     ap.add_argument("--steps", type=int, default=64)
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--workload", default="cfg4_10Mtri_4k", choices=sorted(WORKLOADS))
-    ap.add_argument("--traversal", default="culled", choices=["culled", "exact"])
+    ap.add_argument("--traversal", default="culled", choices=["culled", "exact", "wide"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--frames-in-flight", type=int, default=0,
@@ -94,7 +94,7 @@ def main():
     t0 = time.time()
     scene = synthetic_scene(ntri, w, h, seed=12345, textured=textured, nthreads=cores)
     t_scene = time.time() - t0
-    trav = _capi.TRAVERSE_EXACT if args.traversal == "exact" else _capi.TRAVERSE_CULLED
+    trav = {"culled": _capi.TRAVERSE_CULLED, "exact": _capi.TRAVERSE_EXACT, "wide": _capi.TRAVERSE_WIDE}[args.traversal]
     t0 = time.time()
     shader = HIPShader(scene, device=local_rank, rank=rank, world_size=world, traversal=trav,
                        frames_in_flight=args.frames_in_flight)
@@ -194,7 +194,7 @@ def main():
         leaf = cc.leafTests[b] / args.steps
         # bytes a traversal step reads: culled path = one 4-wide node, 7 x 16 B (6 plane vectors + 4 refs);
         # exact path = one binary node of the reference topology, 64 B; a leaf test reads 48 B
-        node_bytes = 112.0 if args.traversal == "culled" else 64.0
+        node_bytes = 112.0 if args.traversal in ("culled", "wide") else 64.0
         requested_bytes = node_bytes * inner + 48.0 * leaf
         # headline `achieved` keeps SURVEY.md §8d's constants (64 B per node step, 48 B per leaf test) whatever the
         # node width, so that rounds stay comparable; the bytes the loads really request are reported beside it
@@ -216,7 +216,7 @@ def main():
         # a node step of the culled path is 7 such loads per lane, a leaf test 3.
         props = torch.cuda.get_device_properties(local_rank)
         clock_hz = float(getattr(props, "clock_rate", 2400000)) * 1e3
-        lane_loads = (7.0 if args.traversal == "culled" else 4.0) * inner + 3.0 * leaf
+        lane_loads = (7.0 if args.traversal in ("culled", "wide") else 4.0) * inner + 3.0 * leaf
         cu_clocks = trace_ms[b] * 1e-3 * clock_hz * props.multi_processor_count
         l1 = {"lane_loads_issued_per_launch": lane_loads,                  # 7 I' + 3 L' from the device counters
               # what the L1 counted for this launch (TCP_TOTAL_CACHE_ACCESSES, profiles/pmc_traffic.json): lanes of a
@@ -227,7 +227,7 @@ def main():
               "ceiling_per_clock_per_cu": 0.87, "ceiling_source": "tools/tcp_rate mode 2 (7 loads per scattered line, L2-resident)",
               "clock_hz": clock_hz, "cus": props.multi_processor_count}
         names = (["k_primary<CULLED, count>", "k_trace_refill<count, 1>", "k_trace_refill<count, 2>", "k_trace_refill<count, 3>"]
-                 if args.traversal == "culled" else ["k_primary<EXACT, count>", "k_trace<EXACT, count> bounce 1",
+                 if args.traversal in ("culled", "wide") else ["k_primary<EXACT, count>", "k_trace<EXACT, count> bounce 1",
                                                      "k_trace<EXACT, count> bounce 2", "k_trace<EXACT, count> bounce 3"])
         roofline = {"bound": "hbm", "kernel": names[b],
                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
@@ -247,6 +247,26 @@ def main():
                                                "shade1": serial_ms[3], "trace2": serial_ms[4], "shade2": serial_ms[5],
                                                "trace3": serial_ms[6], "shade3": serial_ms[7]}
         extra["serial_device_ms_per_frame"] = cc.totalMs / max(1, cc.frames)
+
+    # ---- the same frames without distance culling (RTX_TRAVERSE_WIDE: the reference's leaf set by construction) ----
+    if rank == 0 and world == 1 and args.traversal == "culled":
+        wide = HIPShader(scene, device=local_rank, traversal=_capi.TRAVERSE_WIDE, frames_in_flight=args.frames_in_flight)
+        for i in range(args.warmup):
+            wide.frame_counter = i
+            wide.Render(None, cam)
+        wide.counters(); wide.reset_counters()
+        t1 = time.perf_counter()
+        for i in range(args.steps):
+            if args.orbit:
+                orbit_camera(cam, 0.1 * i, 0.1 * i)
+                wide.frame_counter = 0
+            else:
+                wide.frame_counter = args.warmup + i
+            wide.Render(None, cam)
+        cw = wide.counters()
+        dt = time.perf_counter() - t1
+        extra["without_distance_culling"] = {"traversal": "wide", "mrays_per_s": float(cw.rays) / dt / 1e6, "ms_per_step": dt / args.steps * 1e3}
+        wide.close()
 
     # ---- CPU baseline: the oracle (CPU restatement of ThreadedShader) on a bounded sample ----
     cpu = None

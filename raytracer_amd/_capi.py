@@ -63,7 +63,7 @@ BOX = np.dtype({"names": ["objectID", "parentID", "leftID", "rightID", "min", "m
 TEXTURE = np.dtype({"names": ["width", "height", "offset", "checksum"],
                     "formats": ["<i4", "<i4", "<i4", "<u4"], "offsets": [0, 4, 8, 12], "itemsize": 16})
 
-TRAVERSE_CULLED, TRAVERSE_EXACT = 0, 1
+TRAVERSE_CULLED, TRAVERSE_EXACT, TRAVERSE_WIDE = 0, 1, 2
 SPHERE, TRIANGLE = 0, 4
 
 _f32p = C.POINTER(C.c_float)

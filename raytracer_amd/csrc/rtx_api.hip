@@ -593,6 +593,8 @@ int rtx_create(const RtxSceneDesc* scene, const RtxConfig* cfgIn, RtxRenderer** 
     if (useBVH && !scene->boxes) return fail("boxes is NULL");
 
     Flat flat;
+    if (cfg.traversal != RTX_TRAVERSE_CULLED && cfg.traversal != RTX_TRAVERSE_EXACT && cfg.traversal != RTX_TRAVERSE_WIDE)
+        return fail("RtxConfig.traversal: unknown mode");
     const bool wantFast = cfg.traversal != RTX_TRAVERSE_EXACT;
     PhaseClock createClock;
     if (flatten(*scene, useBVH, wantFast, 16, flat)) return 1;
@@ -656,7 +658,7 @@ int rtx_create(const RtxSceneDesc* scene, const RtxConfig* cfgIn, RtxRenderer** 
     r->sc.rootRef = flat.rootRef;
     r->sc.fast = r->dFast;            // 4-wide nodes, 8 float4 each (NULL unless the mode is CULLED / CULLED_BIG)
     r->sc.fastRoot = flat.fastRoot;
-    r->sc.cullSlack = flat.sliverFraction > 1e-3 ? INFINITY : RTX_CULL_SLACK_DEFAULT;
+    r->sc.cullSlack = (flat.sliverFraction > 1e-3 || cfg.traversal == RTX_TRAVERSE_WIDE) ? INFINITY : RTX_CULL_SLACK_DEFAULT;
     if (const char* e = getenv("RTX_CULL_SLACK")) r->sc.cullSlack = (float)atof(e);      // experiments ("inf" disables culling)
     r->sc.numLeaves = (int)(flat.leaf.size() / 4);
     r->sc.numInner = (int)(flat.inner.size() / 4);

@@ -65,7 +65,7 @@ def test_edge_case_rays(synth_small):
     dirs[7 * k:8 * k, :3] = (1.0, 0.0, 0.0)
     dirs[8 * k:9 * k, :3] = (0.0, -1.0, 0.0)
     want_ids, want_pts, want_nrm = oracle.trace_rays(d, o, dirs)
-    for trav in (_capi.TRAVERSE_CULLED, _capi.TRAVERSE_EXACT):
+    for trav in (_capi.TRAVERSE_CULLED, _capi.TRAVERSE_EXACT, _capi.TRAVERSE_WIDE):
         r = HIPShader(s, traversal=trav)
         ids, pts, nrm = r.trace_rays(o, dirs)
         assert (ids == want_ids).all()

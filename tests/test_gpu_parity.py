@@ -25,7 +25,7 @@ def check_fb(got, want):
 
 
 @pytest.mark.parametrize("name", ["scene1", "scene2"])
-@pytest.mark.parametrize("traversal", [_capi.TRAVERSE_CULLED, _capi.TRAVERSE_EXACT])
+@pytest.mark.parametrize("traversal", [_capi.TRAVERSE_CULLED, _capi.TRAVERSE_EXACT, _capi.TRAVERSE_WIDE])
 def test_golden_scene(name, traversal, request):
     s = request.getfixturevalue(name)
     r = HIPShader(s, traversal=traversal)
@@ -94,7 +94,7 @@ def test_culled_and_exact_traversal_agree_on_incoherent_rays(synth_small):
     dirs[1000:2000, 0] = 0
     v2 = dirs[1000:2000, :3]; dirs[1000:2000, :3] = v2 / np.linalg.norm(v2, axis=1, keepdims=True)
     want_ids, want_pts, want_nrm = oracle.trace_rays(d, o, dirs)
-    for trav in (_capi.TRAVERSE_CULLED, _capi.TRAVERSE_EXACT):
+    for trav in (_capi.TRAVERSE_CULLED, _capi.TRAVERSE_EXACT, _capi.TRAVERSE_WIDE):
         r = HIPShader(s, traversal=trav)
         ids, pts, nrm = r.trace_rays(o, dirs)
         assert (ids == want_ids).all()
@@ -235,7 +235,7 @@ def test_tiny_trees(libs, kind):
     empty slots must never report a hit."""
     s = _tiny_scene(kind)
     d, cam = s.desc(), s.camera
-    for trav in (_capi.TRAVERSE_CULLED, _capi.TRAVERSE_EXACT):
+    for trav in (_capi.TRAVERSE_CULLED, _capi.TRAVERSE_EXACT, _capi.TRAVERSE_WIDE):
         r = HIPShader(s, traversal=trav)
         ids = r.primary_hits(0)
         assert (ids == oracle.primary_hits(d, cam, 0)).all()
