@@ -243,6 +243,22 @@ def main():
                                                  for i in range(4)],
                     "algorithmic_bytes_per_ray_all_trace": (64.0 * sum(cc.innerVisits) + 48.0 * sum(cc.leafTests)) / max(1, all_rays),
                     "vector_l1_front_end": l1}
+        # the reference's own visit counts (its tree, no distance culling, binary nodes) for
+        # the same rays, and the bandwidth they would amount to in this kernel's time ("work-equivalent")
+        if args.traversal != "exact":
+            refc = HIPShader(scene, device=local_rank, rank=rank, world_size=world, traversal=_capi.TRAVERSE_EXACT, count_stats=True,
+                             frames_in_flight=1)
+            refc.frame_counter = args.warmup
+            refc.Render(None, cam)
+            rc = refc.counters()
+            refc.close()
+            ref_inner = [rc.innerVisits[i] / max(1, rc.raysPerBounce[i]) for i in range(4)]
+            ref_leaf = [rc.leafTests[i] / max(1, rc.raysPerBounce[i]) for i in range(4)]
+            rays_b = cc.raysPerBounce[b] / args.steps
+            roofline["reference_semantics"] = {
+                "node_visits_per_ray": ref_inner, "leaf_tests_per_ray": ref_leaf,
+                "work_equivalent_gbs": (64.0 * ref_inner[b] + 48.0 * ref_leaf[b]) * rays_b / (trace_ms[b] * 1e-3) / 1e9 if trace_ms[b] > 0 else 0.0,
+                "note": "visit counts of RTX_TRAVERSE_EXACT (the reference's tree, 64-byte binary nodes) on the same rays; work_equivalent = those bytes over this launch's time"}
         extra["serial_kernel_ms_per_frame"] = {"primary": serial_ms[0], "shade0": serial_ms[1], "trace1": serial_ms[2],
                                                "shade1": serial_ms[3], "trace2": serial_ms[4], "shade2": serial_ms[5],
                                                "trace3": serial_ms[6], "shade3": serial_ms[7]}
