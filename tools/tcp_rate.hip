@@ -3,7 +3,7 @@
 // (b) when 8 neighbouring lanes read the 8 pieces of one 128-byte line ("grouped")? The table is sized to
 // stay in the L1 (16 KiB), the L2 (2 MiB) or the Infinity Cache (128 MiB), so the figure is the cache
 // front-end's, not HBM's.
-//   ./tcp_rate [table_KiB=2048] [mode: 0 scattered, 1 grouped, 2 scattered 7 x same line, 3 scattered 4-byte loads, 4 scattered 8-byte loads] [iters=256]
+//   ./tcp_rate [table_KiB=2048] [mode: 0 scattered, 1 grouped, 2 scattered 7 x same line, 3 scattered 4-byte loads, 4 scattered 8-byte loads, 5 scattered 16-byte buffer loads, 6 = mode 2 with buffer loads] [iters=256]
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -19,7 +19,27 @@ __global__ __launch_bounds__(256) void k_rate(const float4* __restrict__ table, 
     uint32_t h = key * 2654435761u + 12345u;
     float acc = 0.0f;
     for (int it = 0; it < iters; ++it) {
-        if (MODE == 3 || MODE == 4) {
+        if (MODE == 6) {
+            // the traversal's pattern (7 x 16 B of one scattered line per lane) through a buffer resource
+            typedef unsigned int f4_t __attribute__((ext_vector_type(4)));
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)table, (short)0, (int)0x7fffffff, (int)0x00020000);
+            h = h * 1664525u + 1013904223u;
+            const uint32_t off = ((h >> 7) & lineMask) * 128u;
+            f4_t v[7];
+            for (int j = 0; j < 7; ++j) v[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, off + 16u * j, 0, 0);
+            for (int j = 0; j < 7; ++j) acc += __uint_as_float(v[j].x) + __uint_as_float(v[j].w);
+        } else if (MODE == 5) {
+            // the same scattered 16-byte loads through a buffer resource (MUBUF, offen) instead of global_load
+            typedef unsigned int f4_t __attribute__((ext_vector_type(4)));
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)table, (short)0, (int)0x7fffffff, (int)0x00020000);
+            f4_t v[8];
+            for (int k = 0; k < 8; ++k) {
+                h = h * 1664525u + 1013904223u;
+                const uint32_t off = (((h >> 7) & lineMask) * 8u + piece) * 16u;
+                v[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
+            }
+            for (int k = 0; k < 8; ++k) acc += __uint_as_float(v[k].x) + __uint_as_float(v[k].w);
+        } else if (MODE == 3 || MODE == 4) {
             // narrower loads from a line of the lane's own: 4 B (mode 3) or 8 B (mode 4) per lane-load
             float2 v[8];
             for (int k = 0; k < 8; ++k) {
@@ -70,6 +90,8 @@ int main(int argc, char** argv) {
         CHECK(hipEventRecord(t0, 0));
         if (mode == 0) hipLaunchKernelGGL((k_rate<0>), dim3(blocks), dim3(256), 0, 0, table, (uint32_t)(lines - 1), iters, sink);
         else if (mode == 1) hipLaunchKernelGGL((k_rate<1>), dim3(blocks), dim3(256), 0, 0, table, (uint32_t)(lines - 1), iters, sink);
+        else if (mode == 6) hipLaunchKernelGGL((k_rate<6>), dim3(blocks), dim3(256), 0, 0, table, (uint32_t)(lines - 1), iters, sink);
+        else if (mode == 5) hipLaunchKernelGGL((k_rate<5>), dim3(blocks), dim3(256), 0, 0, table, (uint32_t)(lines - 1), iters, sink);
         else if (mode == 3) hipLaunchKernelGGL((k_rate<3>), dim3(blocks), dim3(256), 0, 0, table, (uint32_t)(lines - 1), iters, sink);
         else if (mode == 4) hipLaunchKernelGGL((k_rate<4>), dim3(blocks), dim3(256), 0, 0, table, (uint32_t)(lines - 1), iters, sink);
         else hipLaunchKernelGGL((k_rate<2>), dim3(blocks), dim3(256), 0, 0, table, (uint32_t)(lines - 1), iters, sink);
@@ -78,11 +100,11 @@ int main(int argc, char** argv) {
         float ms = 0; CHECK(hipEventElapsedTime(&ms, t0, t1));
         if (rep > 0 && ms < best) best = ms;
     }
-    const double laneLoads = (double)blocks * 256.0 * iters * (mode == 2 ? 7.0 : 8.0);
+    const double laneLoads = (double)blocks * 256.0 * iters * ((mode == 2 || mode == 6) ? 7.0 : 8.0);
     const double perS = laneLoads / (best * 1e-3);
     const double bytes = mode == 3 ? 4.0 : mode == 4 ? 8.0 : 16.0;
     printf("table %.0f KiB, mode %d (%s): %.1f M lane-loads of %.0f B in %.3f ms -> %.1f G/s = %.2f per clock per CU (%d CUs at %.2f GHz), %.2f TB/s requested\n",
-           lines * 128.0 / 1024.0, mode, mode == 0 ? "scattered" : mode == 1 ? "grouped by 8" : mode == 2 ? "scattered, 7 per line" : mode == 3 ? "scattered dword" : "scattered dwordx2",
+           lines * 128.0 / 1024.0, mode, mode == 0 ? "scattered" : mode == 1 ? "grouped by 8" : mode == 2 ? "scattered, 7 per line" : mode == 3 ? "scattered dword" : mode == 5 ? "scattered, buffer_load" : mode == 6 ? "scattered, 7 per line, buffer_load" : "scattered dwordx2",
            laneLoads / 1e6, bytes, best, perS / 1e9, perS / (cus * ghz * 1e9), cus, ghz, perS * bytes / 1e12);
     return 0;
 }
