@@ -6,7 +6,8 @@
  * File:line citations are relative to the reference tree (DavidSolz/RayTracer).
  *
  * The POD structs below restate the reference's host layouts byte for byte
- * (sizes and offsets are static-asserted in raytracer_amd/csrc/rtx_layout_check.cpp)
+ * (sizes and offsets are asserted in tests/test_abi.py and, against the reference's own
+ * structs, by the static_asserts of oracle/ref_parts.cpp)
  * so that a HIPShader : ComputeShader inside the reference can pass
  * context->objects.data() etc. straight through.
  *

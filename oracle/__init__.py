@@ -20,6 +20,7 @@ class OrcStats(C.Structure):
 
 
 _lib = None
+_lib_ofast = None
 _ref = None
 
 
@@ -28,29 +29,51 @@ def build():
     subprocess.check_call(["make", "-C", _HERE, "-s"])
 
 
+def _bind(path):
+    L = C.CDLL(path)
+    L.orc_render_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                  C.POINTER(OrcStats)]
+    L.orc_render_bands.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(OrcStats)]
+    L.orc_render.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_int]
+    L.orc_primary_hits.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_int, C.c_int]
+    L.orc_primary_rays.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+    L.orc_trace_rays.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                 C.c_int, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.orc_rand.argtypes = [C.POINTER(C.c_uint32)]
+    L.orc_rand.restype = C.c_float
+    L.orc_random_direction.argtypes = [C.POINTER(C.c_uint32), C.c_void_p]
+    L.orc_pixel_position.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    L.orc_shading_terms.argtypes = [C.c_void_p] * 7
+    L.orc_get_texture_pixel.argtypes = [C.c_void_p] * 6
+    L.orc_color_sample.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
+    L.orc_vec_ops.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]
+    L.orc_vec_geom.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]
+    L.orc_color_ops.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]
+    return L
+
+
 def lib():
+    """The strict build (-O2 -ffp-contract=off): the parity oracle."""
     global _lib
     if _lib is None:
         path = os.path.join(_HERE, "liboracle.so")
         if not os.path.exists(path):
             build()
-        L = C.CDLL(path)
-        L.orc_render_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
-                                      C.POINTER(OrcStats)]
-        L.orc_render.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_int]
-        L.orc_primary_hits.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_int, C.c_int]
-        L.orc_primary_rays.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
-        L.orc_trace_rays.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p,
-                                     C.c_int, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
-        L.orc_rand.argtypes = [C.POINTER(C.c_uint32)]
-        L.orc_rand.restype = C.c_float
-        L.orc_random_direction.argtypes = [C.POINTER(C.c_uint32), C.c_void_p]
-        L.orc_pixel_position.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
-        L.orc_shading_terms.argtypes = [C.c_void_p] * 7
-        L.orc_get_texture_pixel.argtypes = [C.c_void_p] * 6
-        L.orc_color_sample.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
-        _lib = L
+        _lib = _bind(path)
     return _lib
+
+
+def lib_ofast():
+    """The same source with the reference's shipped flags (-Ofast, CMakeLists.txt:11). Never a parity oracle (its
+    rsqrtss-based Normalize is host-dependent): used to reproduce the reference's recorded -Ofast outputs and as the
+    faster end of the CPU baseline bracket. None if not built."""
+    global _lib_ofast
+    if _lib_ofast is None:
+        path = os.path.join(_HERE, "liboracle_ofast.so")
+        if not os.path.exists(path):
+            return None
+        _lib_ofast = _bind(path)
+    return _lib_ofast
 
 
 def ref_parts():
@@ -81,19 +104,29 @@ def _p(x):
     return C.byref(x) if isinstance(x, C.Structure) else x
 
 
-def render(desc, cam, frame_counter, pixels, nthreads=8, rows=None, stats=0):
+def render(desc, cam, frame_counter, pixels, nthreads=8, rows=None, stats=0, L=None):
     """One ThreadedShader::Render over `pixels` (h*w*4 float32, updated in place)."""
     assert pixels.dtype == np.float32 and pixels.flags.c_contiguous
     y0, y1 = (0, desc.height) if rows is None else rows
     st = OrcStats()
-    lib().orc_render_rows(C.byref(desc), C.byref(cam), frame_counter, pixels.ctypes.data, y0, y1, nthreads, stats,
-                          C.byref(st))
+    (L or lib()).orc_render_rows(C.byref(desc), C.byref(cam), frame_counter, pixels.ctypes.data, y0, y1, nthreads, stats,
+                                 C.byref(st))
     return st
 
 
-def primary_hits(desc, cam, frame_counter=0, mode=0, nthreads=8):
+def render_bands(desc, cam, frame_counter, pixels, nthreads=8, rows=None, L=None):
+    """The same with ThreadedShader::Render's own schedule: static contiguous row bands, one thread each
+    (src/ThreadedShader.cpp:186-207). Returns ray statistics."""
+    assert pixels.dtype == np.float32 and pixels.flags.c_contiguous
+    y0, y1 = (0, desc.height) if rows is None else rows
+    st = OrcStats()
+    (L or lib()).orc_render_bands(C.byref(desc), C.byref(cam), frame_counter, pixels.ctypes.data, y0, y1, nthreads, C.byref(st))
+    return st
+
+
+def primary_hits(desc, cam, frame_counter=0, mode=0, nthreads=8, L=None):
     ids = np.empty((desc.height, desc.width), dtype=np.int32)
-    lib().orc_primary_hits(C.byref(desc), C.byref(cam), frame_counter, ids.ctypes.data, mode, nthreads)
+    (L or lib()).orc_primary_hits(C.byref(desc), C.byref(cam), frame_counter, ids.ctypes.data, mode, nthreads)
     return ids
 
 

@@ -1,10 +1,11 @@
 // rtx_device.h — device-side data layout and arithmetic of the HIP backend.
 //
 // HBM layout (all arrays 64-byte aligned, read-only during a frame):
-//   inner[]   64 B / inner node : the reference's topology (pre-order), both children's AABBs + both child refs
-//   fast[]    64 B / inner node : same leaves indexed by a binned-SAH tree built in rtx_create (rtx_build.h)
+//   inner[]   64 B / inner node : the reference's topology (pre-order), both children's AABBs + both child refs:
 //             q0 = (lo0.x lo0.y lo0.z hi0.x) q1 = (hi0.y hi0.z lo1.x lo1.y)
 //             q2 = (lo1.z hi1.x hi1.y hi1.z) q3 = (ref0 ref1 - -)      ref>=0 inner, ref<0 leaf ~ref
+//   fast[]   128 B / 4-wide node: the renderer's own SAH tree over the same leaves (rtx_build.h Node4):
+//             lo.x[4] hi.x[4] lo.y[4] hi.y[4] lo.z[4] hi.z[4] ref[4] pad[4]; an empty slot holds a NaN box
 //   leaf[]    64 B / primitive  : q0 = (A.x A.y A.z e1.x) q1 = (e1.y e1.z e2.x e2.y) q2 = (e2.z boxID<<3|type - -)
 //             sphere: A = centre, e1.x = radius. A leaf test reads the first 40 bytes (three lane loads).
 //   shade[]  128 B / primitive  : q0 q1 as in leaf[], q2 = (e2.z objectID boxID type) q3 = (B.x B.y C.x C.y),
@@ -59,7 +60,7 @@ __device__ __forceinline__ float rtx_rand(uint32_t& seed) {
 }
 
 struct DevScene {
-    const float4* fast;   // own SAH tree over the same leaves (may be NULL); same record layout as inner[]
+    const float4* fast;   // own 4-wide SAH tree over the same leaves (may be NULL): 8 float4 per node (rtx_build.h Node4)
     int fastRoot;
     const float4* inner;
     const float4* leaf;

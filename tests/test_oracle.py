@@ -125,6 +125,72 @@ def test_texture_fetch_bit_exact(scene1):
             assert (bits(a) == bits(b)).all()
 
 
+def same_bits_or_both_nan(a, b):
+    """Bit equality; two NaNs count as equal whatever their payload (the payload of x86's NaN results depends on
+    the operand order the compiler picked for a commutative SSE instruction, not on the arithmetic)."""
+    a = np.ascontiguousarray(a, np.float32); b = np.ascontiguousarray(b, np.float32)
+    return bool(((bits(a) == bits(b)) | (np.isnan(a) & np.isnan(b))).all())
+
+
+SPECIALS = np.array([0.0, -0.0, 1.0, -1.0, 0.5, 1.0000001, 0.99999994, 2.0, 1e-45, -1e-45, 1.1754942e-38, 1e-38, 3.4028235e38,
+                     -3.4028235e38, np.inf, -np.inf, np.nan, 1e-6, -1e-6, 0.01, 1e20, 1e-20, 255.0, 3.1415926535], np.float32)
+
+
+def primitive_cases():
+    """Operand pairs for the Vector3 / Color primitives: random vectors at several magnitudes, every pair of special
+    values broadcast into single lanes (NaN, +-inf, +-0, denormals, FLT_MAX), zero-length and huge vectors."""
+    r = np.random.default_rng(77)
+    cases = []
+    for scale in (1.0, 1e-3, 1e3, 1e-20, 1e18):
+        for _ in range(200):
+            cases.append((r.normal(size=4).astype(np.float32) * np.float32(scale), r.normal(size=4).astype(np.float32) * np.float32(scale),
+                          np.float32(r.uniform(-0.5, 1.5))))
+    for i, x in enumerate(SPECIALS):
+        for j, y in enumerate(SPECIALS):
+            a = r.normal(size=4).astype(np.float32); b = r.normal(size=4).astype(np.float32)
+            a[(i + j) % 4] = x; b[(i + j) % 4] = y
+            cases.append((a, b, SPECIALS[(i * 7 + j) % len(SPECIALS)]))
+            cases.append((np.full(4, x, np.float32), np.full(4, y, np.float32), y))
+    z = np.zeros(4, np.float32)
+    cases += [(z, z, np.float32(0.5)), (z, np.ones(4, np.float32), np.float32(np.nan)), (np.full(4, 1e30, np.float32), z, np.float32(2.0)),
+              (np.array([1e-30, 0, 0, 5], np.float32), z, np.float32(-1.0)), (np.array([0, 0, 0, 7], np.float32), z, np.float32(1.0))]
+    return cases
+
+
+@needs_ref
+def test_vector_and_color_primitives_bit_exact():
+    """src/Vector3.h:34-52 (Dot, Cross, Lerp with its in-place clamp of t), :54-91 (SSE Minimal/Maximal/Clamp: the SECOND
+    operand wins when either is NaN), :93-174 (+ - * / on all four lanes, / multiplies by 1.0f/s), :184-199 (Magnitude over
+    xyz, Normalize scales all four lanes); src/Color.h:15-78 (+ - *), :95-98 (Lerp, std::fmax/fmin), :109-122 (Clamp).
+    The oracle's add/sub/mul/divs/sse_min/sse_max/clamp01_sse/dot/cross/normalize/clamp01_libm+lerp_v/lerp_c against the
+    reference's own code compiled where it lies (oracle/_ref/libref_parts.so). With this, every function of
+    ThreadedShader.cpp that the oracle restates is a composition of reference-pinned primitives, libm calls and control flow."""
+    L = oracle.lib()
+    n = 0
+    for a, b, t in primitive_cases():
+        a = np.ascontiguousarray(a, np.float32); b = np.ascontiguousarray(b, np.float32)
+        for fn, size in (("vec_ops", 32), ("vec_geom", 15), ("color_ops", 12)):
+            got, want = np.zeros(size, np.float32), np.zeros(size, np.float32)
+            getattr(L, "orc_" + fn)(a.ctypes.data, b.ctypes.data, C.c_float(float(t)), got.ctypes.data)
+            getattr(ref, "ref_" + fn)(a.ctypes.data, b.ctypes.data, C.c_float(float(t)), want.ctypes.data)
+            assert same_bits_or_both_nan(got, want), (fn, a, b, t, got, want)
+        n += 1
+    assert n > 2000
+
+
+def test_sse_nan_rule_is_the_second_operand():
+    """The rule itself, independent of the reference build: _mm_min_ps(a, b) = a < b ? a : b."""
+    L = oracle.lib()
+    a = np.array([np.nan, 1.0, np.nan, 2.0], np.float32); b = np.array([3.0, np.nan, np.nan, 1.0], np.float32)
+    out = np.zeros(32, np.float32)
+    L.orc_vec_ops(a.ctypes.data, b.ctypes.data, C.c_float(1.0), out.ctypes.data)
+    mn, mx, cl = out[20:24], out[24:28], out[28:32]
+    assert mn[0] == 3.0 and np.isnan(mn[1]) and np.isnan(mn[2]) and mn[3] == 1.0
+    assert mx[0] == 3.0 and np.isnan(mx[1]) and np.isnan(mx[2]) and mx[3] == 2.0
+    # Clamp(NaN) = max(min(NaN, 1), 0) = max(1, 0) = 1: how a degenerate triangle's texture coordinates become (1, 1)
+    assert cl[0] == 1.0 and cl[1] == 1.0 and cl[2] == 1.0 and cl[3] == 1.0
+
+
 @pytest.mark.skipif(not have_reference(), reason="needs /root/reference (build container only)")
 @needs_ref
 @pytest.mark.skipif(not have_reference(), reason="needs the bundled textures under /root/reference")
@@ -167,6 +233,57 @@ def test_recorded_reference_outputs_2scn():
     # material 0 (the floor) has uninitialised fields in the reference (src/Configurator.cpp:24-36),
     # so only agreement to ~1e-6 relative can be expected; the -Ofast build is 46 away
     assert abs(rgb_sum - 1040022.3) < 1.0, rgb_sum
+
+
+@pytest.mark.skipif(not have_reference(), reason="needs /root/reference (build container only)")
+def test_recorded_reference_outputs_2scn_ofast_build():
+    """The reference's second recorded pair: its as-shipped -Ofast build gave 550 057
+    primary hits and a 1000x1000 one-frame RGB sum of 1039975.7. oracle/rt_oracle.cpp compiled with -Ofast
+    (oracle/liboracle_ofast.so) reproduces both — so the one restatement, compiled two ways, lands on the reference's
+    numbers for both of its builds. -Ofast turns Normalize's 1.0f/sqrtf into rsqrtss + a Newton step, whose bits depend on
+    the CPU; on a host whose estimate differs from the survey's the test reports instead of failing."""
+    from raytracer_amd.scene import HostScene
+    L = oracle.lib_ofast()
+    assert L is not None, "oracle/liboracle_ofast.so not built (make -C oracle)"
+    scn = os.path.join(REFERENCE, "resources/scenes/2.scn")
+    s = HostScene(1000, 1000).load_scn(scn).build_bvh(4)
+    ids = oracle.primary_hits(s.desc(), s.camera, 0, mode=1, L=L)
+    hits = int((ids >= 0).sum())
+    s2 = HostScene(1000, 1000).set_resolution(1000, 1000).load_scn(scn).build_bvh(4)
+    px = np.zeros((1000, 1000, 4), np.float32)
+    oracle.render(s2.desc(), s2.camera, 0, px, 8, L=L)
+    rgb_sum = float(px[..., :3].astype(np.float64).sum())
+    if hits != 550057 or abs(rgb_sum - 1039975.7) >= 1.0:
+        pytest.xfail(f"-Ofast build on this host: {hits} hits, sum {rgb_sum} (recorded on the survey host: 550057, 1039975.7)")
+    # and the two builds really differ where the reference's two builds differed: a handful of silhouette pixels
+    strict = oracle.primary_hits(s.desc(), s.camera, 0, mode=1)
+    assert 0 < int((ids != strict).sum()) < 5000
+
+
+@pytest.mark.skipif(not have_reference(), reason="needs /root/reference (build container only)")
+def test_recorded_hashes_are_not_reproduced_by_any_obvious_convention():
+    """BASELINE.md §2 also quotes hashes of the reference's ID map (07544e4368e87eca) and framebuffer (79a2746fda3ea8c6,
+    -O2) without saying how they were computed. scripts/hash_probe.py tries FNV-1a-64 / FNV-1-64 / FNV-1a-32 over bytes and
+    over words, for int32 / +1 / int64 / big-endian / hit-mask / int16 / float / column-major / bottom-up layouts: none
+    matches (the framebuffer cannot: the floor's material 0 has uninitialised fields in the reference,
+    src/Configurator.cpp:24-36). This test keeps that outcome honest: if a convention ever matches, it fails and the
+    match should become a real pin. Until then those two quantities are PARITY UNPINNED beyond the hit count and the sum."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("hash_probe", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "hash_probe.py"))
+    hp = importlib.util.module_from_spec(spec); spec.loader.exec_module(hp)
+    from raytracer_amd.scene import HostScene
+    s = HostScene(1000, 1000).load_scn(os.path.join(REFERENCE, "resources/scenes/2.scn")).build_bvh(4)
+    ids = oracle.primary_hits(s.desc(), s.camera, 0, mode=1)
+    assert hp.try_all(hp.id_layouts(ids), "07544e4368e87eca") == []
+
+
+def test_static_bands_render_the_same_pixels(scene2):
+    """orc_render_bands (ThreadedShader::Render's schedule, src/ThreadedShader.cpp:186-207) == the dynamic hand-out."""
+    d, cam = scene2.desc(), scene2.camera
+    a = np.zeros((d.height, d.width, 4), np.float32); b = np.zeros_like(a)
+    sa = oracle.render(d, cam, 2, a, 4, stats=1)
+    sb = oracle.render_bands(d, cam, 2, b, 3)
+    assert (bits(a) == bits(b)).all() and sa.rays == sb.rays
 
 
 @pytest.mark.parametrize("name", ["scene1", "scene2"])
