@@ -124,14 +124,15 @@ typedef struct RtxSceneDesc {
     int32_t  _pad;
 } RtxSceneDesc;
 
-enum { RTX_TRAVERSE_CULLED = 0,   /* own 4-wide SAH tree, nearest child first, distance culling with a per-scene slack (none on
-                                     sliver geometry): same closest hit + tie-break unless a grazing triangle's computed t
-                                     undercuts its own box's computed entry distance by more than the slack (DESIGN.md 3.1;
-                                     none found in 140 M rays / 3800 randomised scenes) */
+enum { RTX_TRAVERSE_WIDE   = 0,   /* DEFAULT. Own 4-wide SAH tree over the reference's leaves, NO distance culling: tests
+                                     exactly the leaves the reference tests (a leaf is tested iff its own box passes,
+                                     DESIGN.md 3.1), same t arithmetic, same tie-break: the reference's result by
+                                     construction, for every input */
        RTX_TRAVERSE_EXACT  = 1,   /* the reference's own tree and visit order: no distance culling, no reordering */
-       RTX_TRAVERSE_WIDE   = 2 }; /* own 4-wide tree, nearest child first, NO distance culling: tests exactly the leaves the
-                                     reference tests (a leaf is tested iff its own box passes), so the result is the
-                                     reference's by construction; 14 % slower than CULLED at 4K / 10 M triangles */
+       RTX_TRAVERSE_CULLED = 2 }; /* opt-in. WIDE's tree walked nearest child first with distance culling (per-scene
+                                     slack, none on sliver geometry): same result unless a grazing triangle's computed t
+                                     undercuts its own box's computed entry distance by more than the slack — a bet, not a
+                                     proof (none found in 140 M rays / 3800 randomised scenes) */
 
 typedef struct RtxConfig {
     int32_t device;        /* HIP device ordinal */
@@ -168,6 +169,25 @@ typedef struct RtxCounters {
                                  launches only): (innerVisits + leafTests) / (64 * wavePasses) = work items per lane-pass
                                  (a lane can do a node step and a leaf test in one pass) */
 } RtxCounters;
+
+/* What rtx_create decided (no reference counterpart; diagnostics for callers and benchmarks). */
+typedef struct RtxInfo {
+    int32_t  traversal;        /* RTX_TRAVERSE_* actually in effect (EXACT when the caller's boxes break the own tree's
+                                  preconditions, or without a BVH: then `linear` is set) */
+    int32_t  linear;           /* 1: no BVH, the list is walked in object order (src/ThreadedShader.cpp:15-19) */
+    int32_t  bigNodes;         /* 1: 64-bit node addressing (more than 2^25 wide nodes) */
+    float    cullSlack;        /* relative slack of distance culling; +inf = no culling */
+    int32_t  framesInFlight;   /* frame contexts (streams) the renderer holds */
+    int32_t  framesPerBatch;   /* queued frames rendered by one set of launches */
+    int32_t  hwQueues;         /* GPU_MAX_HW_QUEUES as seen at create (HIP's default 4 when unset) */
+    int32_t  refTreeDepth;     /* depth of the caller's tree */
+    int32_t  wideTreeDepth;    /* depth of the own 4-wide tree (0 when absent) */
+    int32_t  stackEntries;     /* traversal stack entries a lane can need */
+    uint64_t leaves, innerNodes, wideNodes;
+    double   sliverFraction;   /* triangles with longest edge^2 / (2 area) > 32 */
+    uint64_t deviceBytes;      /* device memory held by this renderer */
+    double   createSeconds[4]; /* validate + walk boxes, own-tree build, record emission, upload + allocation */
+} RtxInfo;
 
 typedef struct RtxRenderer RtxRenderer;
 
@@ -211,6 +231,7 @@ int rtx_upload_pixels(RtxRenderer* r, const float* pixels_rgba);
 int rtx_download_pixels(RtxRenderer* r, float* pixels_rgba);
 int rtx_clear_pixels(RtxRenderer* r);
 
+int  rtx_get_info(RtxRenderer* r, RtxInfo* out);
 int  rtx_get_counters(RtxRenderer* r, RtxCounters* out);
 int  rtx_reset_counters(RtxRenderer* r);
 void rtx_destroy(RtxRenderer* r);

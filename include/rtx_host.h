@@ -65,6 +65,13 @@ int rtxh_scene_add_heightfield(RtxHostScene* s, uint64_t ntri, uint32_t seed,
                                float extentU, float extentV, float amplitude, float tiltDeg,
                                float cx, float cy, float cz,
                                const int32_t* materialIDs, int32_t numMaterialIDs);
+/* The same mesh written as Wavefront OBJ text ("v", "vn", "usemtl <name>", "f a//a b//b c//c"; the materials must
+ * have names in `s`): the route the reference itself takes for meshes (src/MeshSerializer.cpp:141-243). Loading the
+ * file with rtxh_scene_load_obj into a scene of the same resolution gives byte-identical objects. */
+int rtxh_write_heightfield_obj(RtxHostScene* s, const char* path, uint64_t ntri, uint32_t seed,
+                               float extentU, float extentV, float amplitude, float tiltDeg,
+                               float cx, float cy, float cz,
+                               const int32_t* materialIDs, int32_t numMaterialIDs);
 
 /* Replaces BVHTree::BuildBVH (src/BVHTree.cpp:42-60,148-195): same tree (median
  * split by std::nth_element on position[depth%3], one object per leaf, 2N-1

@@ -46,6 +46,14 @@ class Counters(C.Structure):
                 ("totalMs", C.c_double), ("kernelMs", C.c_double * 8), ("wavePasses", C.c_uint64 * 4)]
 
 
+class Info(C.Structure):
+    _fields_ = [("traversal", C.c_int32), ("linear", C.c_int32), ("bigNodes", C.c_int32), ("cullSlack", C.c_float),
+                ("framesInFlight", C.c_int32), ("framesPerBatch", C.c_int32), ("hwQueues", C.c_int32),
+                ("refTreeDepth", C.c_int32), ("wideTreeDepth", C.c_int32), ("stackEntries", C.c_int32),
+                ("leaves", C.c_uint64), ("innerNodes", C.c_uint64), ("wideNodes", C.c_uint64),
+                ("sliverFraction", C.c_double), ("deviceBytes", C.c_uint64), ("createSeconds", C.c_double * 4)]
+
+
 # numpy mirrors of the reference PODs (sizes/offsets as in include/rtx.h)
 VEC4 = np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("w", "<f4")])
 OBJECT = np.dtype({"names": ["type", "radius", "position", "normals", "vertices", "uvs", "materialID"],
@@ -63,7 +71,7 @@ BOX = np.dtype({"names": ["objectID", "parentID", "leftID", "rightID", "min", "m
 TEXTURE = np.dtype({"names": ["width", "height", "offset", "checksum"],
                     "formats": ["<i4", "<i4", "<i4", "<u4"], "offsets": [0, 4, 8, 12], "itemsize": 16})
 
-TRAVERSE_CULLED, TRAVERSE_EXACT, TRAVERSE_WIDE = 0, 1, 2
+TRAVERSE_WIDE, TRAVERSE_EXACT, TRAVERSE_CULLED = 0, 1, 2
 SPHERE, TRIANGLE = 0, 4
 
 _f32p = C.POINTER(C.c_float)
@@ -106,6 +114,8 @@ def host_lib():
                                           C.c_uint64, C.c_int]
         L.rtxh_scene_add_heightfield.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_float, C.c_float, C.c_float,
                                                  C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_int32]
+        L.rtxh_write_heightfield_obj.argtypes = [C.c_void_p, C.c_char_p, C.c_uint64, C.c_uint32, C.c_float, C.c_float, C.c_float,
+                                                 C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_int32]
         L.rtxh_scene_build_bvh.argtypes = [C.c_void_p, C.c_int]
         L.rtxh_scene_desc.argtypes = [C.c_void_p, C.POINTER(SceneDesc)]
         L.rtxh_scene_camera.argtypes = [C.c_void_p, C.POINTER(Camera)]
@@ -135,6 +145,7 @@ def hip_lib():
             getattr(L, fn).argtypes = [C.c_void_p, C.c_void_p]
         L.rtx_clear_pixels.argtypes = [C.c_void_p]
         L.rtx_get_counters.argtypes = [C.c_void_p, C.POINTER(Counters)]
+        L.rtx_get_info.argtypes = [C.c_void_p, C.POINTER(Info)]
         L.rtx_reset_counters.argtypes = [C.c_void_p]
         L.rtx_destroy.argtypes = [C.c_void_p]
         L.rtx_destroy.restype = None
@@ -157,12 +168,12 @@ def hip_lib():
 
 
 EXPORTED_HIP = ["rtx_create", "rtx_render", "rtx_primary_hits", "rtx_trace_rays", "rtx_upload_pixels",
-                "rtx_download_pixels", "rtx_clear_pixels", "rtx_get_counters", "rtx_reset_counters", "rtx_destroy",
+                "rtx_download_pixels", "rtx_clear_pixels", "rtx_get_info", "rtx_get_counters", "rtx_reset_counters", "rtx_destroy",
                 "rtx_last_error", "rtx_framebuffer_device_ptr", "rtx_stream", "rtx_local_pixel_count",
                 "rtx_local_tile_count", "rtx_packed_floats", "rtx_pack_tiles", "rtx_unpack_tiles", "rtx_version"]
 EXPORTED_HOST = ["rtxh_scene_new", "rtxh_scene_free", "rtxh_scene_set_resolution", "rtxh_scene_load_scn", "rtxh_scene_load_mtl",
                  "rtxh_scene_load_obj", "rtxh_scene_material_id", "rtxh_scene_add_texture", "rtxh_scene_add_material",
                  "rtxh_scene_add_plane", "rtxh_scene_add_disk", "rtxh_scene_add_cube", "rtxh_scene_add_sphere",
-                 "rtxh_scene_add_mesh", "rtxh_scene_add_heightfield", "rtxh_scene_build_bvh", "rtxh_scene_from_arrays", "rtxh_scene_desc",
+                 "rtxh_scene_add_mesh", "rtxh_scene_add_heightfield", "rtxh_write_heightfield_obj", "rtxh_scene_build_bvh", "rtxh_scene_from_arrays", "rtxh_scene_desc",
                  "rtxh_scene_camera", "rtxh_scene_set_camera", "rtxh_camera_look_at", "rtxh_camera_orbit",
                  "rtxh_scene_save_blob", "rtxh_scene_load_blob", "rtxh_last_error"]

@@ -99,6 +99,10 @@ int rtxh_scene_add_heightfield(RtxHostScene* h, uint64_t ntri, uint32_t seed, fl
     add_heightfield(h->s, ntri, seed, extentU, extentV, amplitude, tiltDeg, cx, cy, cz, mats, nmats);
     return 0;
 }
+int rtxh_write_heightfield_obj(RtxHostScene* h, const char* path, uint64_t ntri, uint32_t seed, float extentU, float extentV,
+                               float amplitude, float tiltDeg, float cx, float cy, float cz, const int32_t* mats, int32_t nmats) {
+    return write_heightfield_obj(h->s, path, ntri, seed, extentU, extentV, amplitude, tiltDeg, cx, cy, cz, mats, nmats) ? 0 : fail(get_error());
+}
 
 int rtxh_scene_build_bvh(RtxHostScene* h, int nthreads) { build_bvh(h->s, nthreads < 1 ? 1 : nthreads); return 0; }
 

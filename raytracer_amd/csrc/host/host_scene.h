@@ -63,6 +63,8 @@ void add_mesh(HostScene& s, const float* vertices, const float* normals, uint64_
               const uint32_t* indices, const int32_t* materialIDs, uint64_t ntri, int materialID0);
 void add_heightfield(HostScene& s, uint64_t ntri, uint32_t seed, float extentU, float extentV, float amplitude,
                      float tiltDeg, float cx, float cy, float cz, const int32_t* mats, int32_t nmats);
+bool write_heightfield_obj(const HostScene& s, const std::string& path, uint64_t ntri, uint32_t seed, float extentU, float extentV,
+                           float amplitude, float tiltDeg, float cx, float cy, float cz, const int32_t* mats, int32_t nmats);
 const std::string& get_error();
 
 } // namespace rtxh

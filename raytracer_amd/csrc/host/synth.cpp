@@ -6,7 +6,10 @@
 // to floats by explicit arithmetic only.
 #include "host_scene.h"
 
+#include <cstdio>
+#include <map>
 #include <random>
+#include <string>
 #include <thread>
 
 namespace rtxh {
@@ -43,9 +46,19 @@ static inline uint32_t mix32(uint32_t x) {
     return x;
 }
 
-void add_heightfield(HostScene& s, uint64_t ntri, uint32_t seed, float extentU, float extentV, float amplitude,
-                     float tiltDeg, float cx, float cy, float cz, const int32_t* mats, int32_t nmats) {
-    if (ntri == 0) return;
+namespace {
+struct HeightField {
+    std::vector<float> verts, norms;      // OBJ space, 3 floats per vertex
+    std::vector<uint32_t> idx;            // 3 per triangle
+    std::vector<int32_t> mid;             // material per triangle
+    uint64_t nv = 0;
+};
+}
+
+static HeightField gen_heightfield(uint64_t ntri, uint32_t seed, float extentU, float extentV, float amplitude,
+                                   float tiltDeg, float cx, float cy, float cz, const int32_t* mats, int32_t nmats) {
+    HeightField out;
+    if (ntri == 0) return out;
     // cells = ceil(ntri/2); pick the factor pair of cells closest to extentU:extentV
     const uint64_t cells = (ntri + 1) / 2;
     const double want = std::sqrt((double)cells * (double)extentU / (double)extentV);
@@ -72,7 +85,8 @@ void add_heightfield(HostScene& s, uint64_t ntri, uint32_t seed, float extentU, 
     const float tilt = tiltDeg * 0.0174532925f;
     const float ct = cosf(tilt), st = sinf(tilt);
     const uint64_t nvu = gu + 1, nvv = gv + 1;
-    std::vector<float> verts(3 * nvu * nvv), norms(3 * nvu * nvv);
+    std::vector<float>& verts = out.verts; std::vector<float>& norms = out.norms;
+    verts.resize(3 * nvu * nvv); norms.resize(3 * nvu * nvv);
     const float du = extentU / (float)gu, dv = extentV / (float)gv;
     for (uint64_t j = 0; j < nvv; ++j)
         for (uint64_t i = 0; i < nvu; ++i) {
@@ -97,8 +111,8 @@ void add_heightfield(HostScene& s, uint64_t ntri, uint32_t seed, float extentU, 
             verts[o] = cx + lx; verts[o + 1] = cy + ly * ct - lz * st; verts[o + 2] = cz + ly * st + lz * ct;
             norms[o] = nx;      norms[o + 1] = ny * ct - nz * st;      norms[o + 2] = ny * st + nz * ct;
         }
-    std::vector<uint32_t> idx(3 * ntri);
-    std::vector<int32_t> mid(ntri);
+    std::vector<uint32_t>& idx = out.idx; std::vector<int32_t>& mid = out.mid;
+    idx.resize(3 * ntri); mid.resize(ntri);
     uint64_t f = 0;
     for (uint64_t j = 0; j < gv && f < ntri; ++j)
         for (uint64_t i = 0; i < gu && f < ntri; ++i) {
@@ -107,7 +121,48 @@ void add_heightfield(HostScene& s, uint64_t ntri, uint32_t seed, float extentU, 
             idx[3 * f] = a; idx[3 * f + 1] = c; idx[3 * f + 2] = b; mid[f++] = m;
             if (f < ntri) { idx[3 * f] = b; idx[3 * f + 1] = c; idx[3 * f + 2] = d; mid[f++] = m; }
         }
-    add_mesh(s, verts.data(), norms.data(), nvu * nvv, idx.data(), mid.data(), ntri, 0);
+    out.nv = nvu * nvv;
+    return out;
+}
+
+void add_heightfield(HostScene& s, uint64_t ntri, uint32_t seed, float extentU, float extentV, float amplitude,
+                     float tiltDeg, float cx, float cy, float cz, const int32_t* mats, int32_t nmats) {
+    if (ntri == 0) return;
+    const HeightField hf = gen_heightfield(ntri, seed, extentU, extentV, amplitude, tiltDeg, cx, cy, cz, mats, nmats);
+    add_mesh(s, hf.verts.data(), hf.norms.data(), hf.nv, hf.idx.data(), hf.mid.data(), ntri, 0);
+}
+
+// The same mesh as Wavefront OBJ text, the route the reference itself takes (mesh <file>.obj in a .scn,
+// src/SceneSerializer.cpp:226-234 -> src/MeshSerializer.cpp:141-243): "v", "vn", "usemtl <name>" whenever the material
+// changes, "f a//a b//b c//c". Coordinates are printed with 9 significant digits, which atof + the cast to float
+// (src/MeshSerializer.cpp:150-152) map back to the very same float, so load_obj of this file yields byte-identical
+// objects to add_heightfield (tests/test_host_scene.py, tests/test_gpu_configs.py: cfg3).
+bool write_heightfield_obj(const HostScene& s, const std::string& path, uint64_t ntri, uint32_t seed, float extentU, float extentV,
+                           float amplitude, float tiltDeg, float cx, float cy, float cz, const int32_t* mats, int32_t nmats) {
+    const HeightField hf = gen_heightfield(ntri, seed, extentU, extentV, amplitude, tiltDeg, cx, cy, cz, mats, nmats);
+    std::map<int32_t, std::string> nameOf;
+    for (const auto& kv : s.materialNames) nameOf[(int32_t)kv.second] = kv.first;
+    FILE* f = fopen(path.c_str(), "w");
+    if (!f) { set_error("cannot write " + path); return false; }
+    std::vector<char> buf(1 << 20);
+    setvbuf(f, buf.data(), _IOFBF, buf.size());
+    fprintf(f, "# synthetic height field, %llu triangles, seed %u\n", (unsigned long long)ntri, seed);
+    for (uint64_t i = 0; i < hf.nv; ++i) fprintf(f, "v %.9g %.9g %.9g\n", hf.verts[3 * i], hf.verts[3 * i + 1], hf.verts[3 * i + 2]);
+    for (uint64_t i = 0; i < hf.nv; ++i) fprintf(f, "vn %.9g %.9g %.9g\n", hf.norms[3 * i], hf.norms[3 * i + 1], hf.norms[3 * i + 2]);
+    int32_t cur = -1;
+    bool ok = true;
+    for (uint64_t t = 0; t < ntri; ++t) {
+        if (hf.mid[t] != cur) {
+            cur = hf.mid[t];
+            auto it = nameOf.find(cur);
+            if (it == nameOf.end()) { set_error("material " + std::to_string(cur) + " has no name to put behind usemtl"); ok = false; break; }
+            fprintf(f, "usemtl %s\n", it->second.c_str());
+        }
+        const uint32_t a = hf.idx[3 * t] + 1, b = hf.idx[3 * t + 1] + 1, c = hf.idx[3 * t + 2] + 1;
+        fprintf(f, "f %u//%u %u//%u %u//%u\n", a, a, b, b, c, c);
+    }
+    if (fclose(f) != 0) { set_error("short write to " + path); ok = false; }
+    return ok;
 }
 
 } // namespace rtxh

@@ -92,6 +92,7 @@ struct RtxRenderer {
     int lastResolved = -1;               // context whose k_resolve was queued last
     uint64_t frameSeq = 0;
     uint64_t primaryRays = 0;            // rays of bounce 0 since the last reset (known on the host)
+    uint64_t deviceBytes = 0;            // device memory allocated by rtx_create
 
     // Frame batches: a rank that owns 1/N of the tiles has queues 1/N as long, and short launches are mostly
     // tail. Frames queued with pixels == NULL are therefore collected and up to `batch` of them rendered by one
@@ -105,6 +106,7 @@ struct RtxRenderer {
     int lastFinished = -1;           // ring slot of the frame whose timing was read last
     int ringPos = 0;
     RtxCounters totals{};
+    RtxInfo info{};
     std::vector<float> hostStage;   // D2H staging for worldSize > 1
     char* hStage = nullptr;         // page-locked staging for delivering the frame to a (pageable) host array
     size_t hStageBytes = 0;
@@ -123,11 +125,16 @@ struct Flat {
     int maxDepth = 0, fastDepth = 0;
     bool nested = true;                 // every box contains its children (precondition of the own tree)
     double sliverFraction = 0.0;        // triangles with longest edge^2 / (2 area) > 32 (or no area at all)
+    double seconds[3] = {0, 0, 0};      // validate + walk, own-tree build, record emission
 };
 
 inline float i2f(int32_t v) { float f; memcpy(&f, &v, 4); return f; }
 
-void emit_leaf(const RtxObject& o, int32_t objectID, int32_t boxID, float4* leaf, float4* shade) {
+// tieRank: the leaf's position in a left-child-first walk of the caller's tree. The reference pops the right child
+// first and accepts a hit only when strictly closer (src/ThreadedShader.cpp:370,380-392), so among equal t the leaf it
+// visits first wins = the one with the LARGEST left-first rank. For trees numbered like BVHTree::Insert numbers them
+// (pre-order, left subtree first, src/BVHTree.cpp:160,180-183) the rank orders leaves exactly like their boxID.
+void emit_leaf(const RtxObject& o, int32_t objectID, int32_t boxID, int32_t tieRank, float4* leaf, float4* shade) {
     const RtxVec4 A = o.vertices[0], B = o.vertices[1], C = o.vertices[2];
     float4 old[4];      // the shading record keeps (e2.z objectID boxID type) / (B.x B.y C.x C.y) in its third and fourth quad
     if (o.type == RTX_TRIANGLE) {
@@ -145,8 +152,9 @@ void emit_leaf(const RtxObject& o, int32_t objectID, int32_t boxID, float4* leaf
         old[2] = make_float4(0, i2f(objectID), i2f(boxID), i2f(o.type));
         old[3] = make_float4(0, 0, 0, 0);
     }
-    // traversal record: the primitive, then boxID and type in one word, so that a leaf test reads 40 contiguous bytes
-    const int32_t tag = (int32_t)(((uint32_t)boxID << 3) | ((uint32_t)o.type & 7u));
+    // traversal record: the primitive, then tie-break rank and type in one word, so that a leaf test reads 40 contiguous
+    // bytes. Every type but TRIANGLE is intersected as a sphere (src/ThreadedShader.cpp:364-368).
+    const int32_t tag = (int32_t)(((uint32_t)tieRank << 3) | (o.type == RTX_TRIANGLE ? 4u : 0u));
     leaf[0] = old[0];
     leaf[1] = old[1];
     leaf[2] = make_float4(old[2].x, i2f(tag), 0.0f, 0.0f);
@@ -167,11 +175,12 @@ const int32_t kNoChild = (int32_t)0x80000000;   // never passes (see traverse_bv
 struct PhaseClock {
     const bool on = getenv("RTX_VERBOSE") != nullptr;
     std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
-    void lap(const char* what) {
-        if (!on) return;
+    double lap(const char* what) {
         const auto now = std::chrono::steady_clock::now();
-        fprintf(stderr, "[rtx]   %-28s %.3f s\n", what, std::chrono::duration<double>(now - t).count());
+        const double sec = std::chrono::duration<double>(now - t).count();
+        if (on) fprintf(stderr, "[rtx]   %-28s %.3f s\n", what, sec);
         t = now;
+        return sec;
     }
 };
 
@@ -232,7 +241,7 @@ int flatten(const RtxSceneDesc& s, bool useBVH, bool wantFast, int nthreads, Fla
     if (!useBVH) {
         f.leaf.resize(nObj * 4); f.shade.resize(nObj * 8);
         parallel_for(nObj, nthreads, [&](uint64_t b, uint64_t e) {
-            for (uint64_t i = b; i < e; ++i) emit_leaf(s.objects[i], (int32_t)i, (int32_t)i, &f.leaf[i * 4], &f.shade[i * 8]);
+            for (uint64_t i = b; i < e; ++i) emit_leaf(s.objects[i], (int32_t)i, (int32_t)i, 0, &f.leaf[i * 4], &f.shade[i * 8]);
         });
         f.rootRef = 0; f.maxDepth = 0;
         return 0;
@@ -256,8 +265,14 @@ int flatten(const RtxSceneDesc& s, bool useBVH, bool wantFast, int nthreads, Fla
         for (uint64_t b = b0; b < b1; ++b) if (s.boxes[b].objectID != -1) leafBox[(size_t)slotOf[b]] = (int32_t)b;
     });
     // depth + tree check (every box reached at most once) + nesting check (parent contains child) + well-formed
-    // boxes. The walk starts breadth-first on one thread; once the frontier is wide enough its subtrees are
-    // walked depth-first on all threads (a box reached twice — by any two walkers — is an error).
+    // boxes + the leaves' tie-break ranks (emit_leaf). The walk starts breadth-first on one thread; once the frontier
+    // is wide enough its subtrees are walked depth-first on all threads (a box reached twice — by any two walkers —
+    // is an error). The frontier keeps the left-to-right order of the tree, a subtree's walker numbers its leaves
+    // locally, and a prefix sum over the frontier turns that into the global left-first rank.
+    if (nLeaf >= (1 << 28)) return fail("too many leaves (2^28 or more)");
+    std::vector<int32_t> rankLocal((size_t)nLeaf, 0), rankPart((size_t)nLeaf, 0);   // per leaf: right-first index inside its part, part
+    std::vector<int64_t> partBase;                                                   // per frontier entry: leaves left of it
+    std::vector<int32_t> partCount;
     {
         std::vector<uint8_t> seen(nBox, 0);
         std::atomic<int> maxDepthAll{0};
@@ -286,45 +301,71 @@ int flatten(const RtxSceneDesc& s, bool useBVH, bool wantFast, int nthreads, Fla
             }
             return true;
         };
-        auto walk = [&](std::vector<std::pair<int32_t, int32_t>>& st) {
+        // depth-first over one part (children are appended left, right and popped from the back: right subtree first)
+        auto walk = [&](std::vector<std::pair<int32_t, int32_t>>& st, int32_t part) -> int32_t {
             int deepest = 0;
+            int32_t leaves = 0;
             while (!st.empty()) {
                 auto [b, depth] = st.back(); st.pop_back();
                 deepest = std::max(deepest, depth);
-                if (!visit(b, depth, st)) return;
+                if (!visit(b, depth, st)) return leaves;
+                if (s.boxes[b].objectID != -1) { rankLocal[(size_t)slotOf[b]] = leaves++; rankPart[(size_t)slotOf[b]] = part; }
             }
             int cur = maxDepthAll.load();
             while (deepest > cur && !maxDepthAll.compare_exchange_weak(cur, deepest)) {}
+            return leaves;
         };
-        std::vector<std::pair<int32_t, int32_t>> frontier{{0, 0}}, next;
+        // breadth-first phase: inner boxes are replaced by their children in place (left, right), leaves stay put
+        std::vector<std::pair<int32_t, int32_t>> frontier{{0, 0}}, next, kids;
+        std::vector<uint8_t> expanded{0}, nextExpanded;      // 1: the entry was visited here and is a leaf
         int topDepth = 0;
-        while (!frontier.empty() && frontier.size() < (size_t)(8 * std::max(1, nthreads)) && !err.any()) {
-            next.clear();
-            for (auto [b, depth] : frontier) { topDepth = std::max(topDepth, depth); if (!visit(b, depth, next)) break; }
-            frontier.swap(next);
+        for (;;) {
+            size_t open = 0;
+            for (size_t i = 0; i < frontier.size(); ++i) open += expanded[i] ? 0 : 1;
+            if (open == 0 || open >= (size_t)(8 * std::max(1, nthreads)) || err.any()) break;
+            next.clear(); nextExpanded.clear();
+            for (size_t i = 0; i < frontier.size() && !err.any(); ++i) {
+                if (expanded[i]) { next.push_back(frontier[i]); nextExpanded.push_back(1); continue; }
+                auto [b, depth] = frontier[i];
+                topDepth = std::max(topDepth, depth);
+                kids.clear();
+                if (!visit(b, depth, kids)) break;
+                if (s.boxes[b].objectID != -1) { next.push_back(frontier[i]); nextExpanded.push_back(1); }
+                else for (auto& k : kids) { next.push_back(k); nextExpanded.push_back(0); }
+            }
+            frontier.swap(next); expanded.swap(nextExpanded);
         }
         maxDepthAll = topDepth;
+        partCount.assign(frontier.size(), 0);
+        for (size_t i = 0; i < frontier.size(); ++i)
+            if (expanded[i]) { partCount[i] = 1; rankLocal[(size_t)slotOf[frontier[i].first]] = 0; rankPart[(size_t)slotOf[frontier[i].first]] = (int32_t)i; }
         if (!err.any() && !frontier.empty()) {
             std::atomic<size_t> nextRoot{0};
             std::vector<std::thread> pool;
             auto worker = [&]() {
                 std::vector<std::pair<int32_t, int32_t>> st;
-                for (size_t i = nextRoot++; i < frontier.size() && !err.any(); i = nextRoot++) { st.assign(1, frontier[i]); walk(st); }
+                for (size_t i = nextRoot++; i < frontier.size() && !err.any(); i = nextRoot++) {
+                    if (expanded[i]) continue;
+                    st.assign(1, frontier[i]);
+                    partCount[i] = walk(st, (int32_t)i);
+                }
             };
             for (int t = 1; t < nthreads; ++t) pool.emplace_back(worker);
             worker();
             for (auto& th : pool) th.join();
         }
         if (err.any()) return fail(err.msg);
+        partBase.assign(frontier.size() + 1, 0);
+        for (size_t i = 0; i < frontier.size(); ++i) partBase[i + 1] = partBase[i] + partCount[i];
         f.maxDepth = maxDepthAll;
         f.nested = nestedAll;
         std::atomic<bool> unreachable{false};
         parallel_for(nBox, nthreads, [&](uint64_t b0, uint64_t b1) {
             for (uint64_t b = b0; b < b1; ++b) if (!seen[b] && s.boxes[b].objectID != -1) { unreachable = true; return; }
         });
-        if (unreachable) f.nested = false;   // unreachable leaf: keep the reference topology
+        if (unreachable) f.nested = false;   // unreachable leaf: keep the reference topology (it is never tested; rank 0)
     }
-    clock.lap("validate + walk boxes");
+    f.seconds[0] = clock.lap("validate + walk boxes");
     // own tree over the same leaf boxes (DESIGN.md "Topology freedom")
     std::vector<uint32_t> order((size_t)nLeaf);
     for (int32_t k = 0; k < nLeaf; ++k) order[k] = (uint32_t)k;
@@ -340,14 +381,14 @@ int flatten(const RtxSceneDesc& s, bool useBVH, bool wantFast, int nthreads, Fla
         std::vector<rtxbuild::Node> bin((size_t)nLeaf - 1);
         int binDepth = 0;
         const int32_t binRoot = rtxbuild::build_sah(prim.data(), (uint32_t)nLeaf, order.data(), bin.data(), nthreads, binDepth);
-        clock.lap("binned-SAH build");
+        f.seconds[1] += clock.lap("binned-SAH build");
         if (binDepth > 60) {
             for (int32_t k = 0; k < nLeaf; ++k) order[k] = (uint32_t)k;      // degenerate input: keep the reference topology
         } else {
             f.fast.reserve((size_t)nLeaf / 2);
             rtxbuild::collapse4(bin.data(), bin.size(), binRoot, f.fast, f.fastDepth, nthreads);
             f.fastRoot = 0;
-            clock.lap("fold into 4-wide nodes");
+            f.seconds[1] += clock.lap("fold into 4-wide nodes");
         }
     } else if (wantFast && f.nested && nLeaf <= 1) {
         rtxbuild::Box b;
@@ -366,7 +407,11 @@ int flatten(const RtxSceneDesc& s, bool useBVH, bool wantFast, int nthreads, Fla
         for (uint64_t p = p0; p < p1; ++p) {
             posOf[order[p]] = (int32_t)p;
             const int32_t b = leafBox[order[p]];
-            emit_leaf(s.objects[s.boxes[b].objectID], s.boxes[b].objectID, b, &f.leaf[(size_t)p * 4], &f.shade[(size_t)p * 8]);
+            // left-first rank = leaves left of the part + (the part walked right subtree first: count - 1 - index)
+            const size_t k = order[p];
+            const int32_t part = rankPart[k];
+            const int32_t rank = (int32_t)std::max<int64_t>(0, partBase[(size_t)part] + (partCount[(size_t)part] - 1 - rankLocal[k]));
+            emit_leaf(s.objects[s.boxes[b].objectID], s.boxes[b].objectID, b, rank, &f.leaf[(size_t)p * 4], &f.shade[(size_t)p * 8]);
         }
     });
     // the reference's own topology (used by RTX_TRAVERSE_EXACT and by lanes that cannot use the own tree)
@@ -393,7 +438,7 @@ int flatten(const RtxSceneDesc& s, bool useBVH, bool wantFast, int nthreads, Fla
       }
     });
     f.rootRef = s.boxes[0].objectID != -1 ? ~posOf[slotOf[0]] : slotOf[0];
-    clock.lap("leaf / shade / inner records");
+    f.seconds[2] = clock.lap("leaf / shade / inner records");
     return 0;
 }
 
@@ -598,6 +643,7 @@ int rtx_create(const RtxSceneDesc* scene, const RtxConfig* cfgIn, RtxRenderer** 
     const bool wantFast = cfg.traversal != RTX_TRAVERSE_EXACT;
     PhaseClock createClock;
     if (flatten(*scene, useBVH, wantFast, 16, flat)) return 1;
+    createClock.lap("flatten");
     if (useBVH && flat.maxDepth > 62) return fail("BVH deeper than 62 levels is not supported (the reference's own stack holds 32)");
 
     RtxRenderer* r = new RtxRenderer();
@@ -619,6 +665,8 @@ int rtx_create(const RtxSceneDesc* scene, const RtxConfig* cfgIn, RtxRenderer** 
     hipDeviceProp_t prop;
     CREATE_HIP(hipGetDeviceProperties(&prop, r->device));
     r->numCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    size_t freeBefore = 0, freeAfter = 0, totalMem = 0;
+    CREATE_HIP(hipMemGetInfo(&freeBefore, &totalMem));
     for (int i = 0; i < kRing; ++i) for (int k = 0; k < kEvents; ++k) CREATE_HIP(hipEventCreate(&r->ev[i][k]));
 
     // tiles: tile t (row-major over the tile grid) belongs to rank t % worldSize
@@ -737,7 +785,22 @@ int rtx_create(const RtxSceneDesc* scene, const RtxConfig* cfgIn, RtxRenderer** 
     for (int b = 0; b < 4; ++b) r->queueHint[b] = r->numSlots * (uint32_t)r->batch;
     set_grids(r, r->numSlots * (uint32_t)r->batch);
     CREATE_HIP(hipDeviceSynchronize());
-    createClock.lap("rtx_create total");
+    {
+        RtxInfo& in = r->info;
+        in.traversal = r->linear ? RTX_TRAVERSE_EXACT : (culled ? (std::isinf(r->sc.cullSlack) ? RTX_TRAVERSE_WIDE : RTX_TRAVERSE_CULLED) : RTX_TRAVERSE_EXACT);
+        in.linear = r->linear ? 1 : 0;
+        in.bigNodes = r->mode == RTX_MODE_CULLED_BIG ? 1 : 0;
+        in.cullSlack = culled ? r->sc.cullSlack : INFINITY;
+        in.framesInFlight = depth; in.framesPerBatch = r->batch; in.hwQueues = hwQueues;
+        in.refTreeDepth = flat.maxDepth; in.wideTreeDepth = flat.fast.empty() ? 0 : flat.fastDepth;
+        in.stackEntries = r->sc.stackDepth;
+        in.leaves = (uint64_t)r->sc.numLeaves; in.innerNodes = (uint64_t)r->sc.numInner; in.wideNodes = flat.fast.size();
+        in.sliverFraction = flat.sliverFraction;
+        if (hipMemGetInfo(&freeAfter, &totalMem) == hipSuccess && freeBefore > freeAfter) r->deviceBytes = freeBefore - freeAfter;
+        in.deviceBytes = r->deviceBytes;
+        for (int k = 0; k < 3; ++k) in.createSeconds[k] = flat.seconds[k];
+        in.createSeconds[3] = createClock.lap("upload + allocation");
+    }
     if (getenv("RTX_VERBOSE"))
         fprintf(stderr, "[rtx] culling slack %g (%.3f %% slivers), %d leaves, reference tree depth %d, own tree %s depth %d, stack %d entries, LDS %zu B/block, %d blocks/CU x %d CUs, mode %d\n",
                 (double)r->sc.cullSlack, 100.0 * flat.sliverFraction, r->sc.numLeaves, flat.maxDepth, flat.fast.empty() ? "absent" : "built", flat.fastDepth, r->sc.stackDepth, r->ldsTrace,
@@ -999,6 +1062,12 @@ int rtx_clear_pixels(RtxRenderer* r) {
     if (sync_all(r)) return 1;
     HIP_TRY(hipMemsetAsync(r->dFb, 0, (size_t)r->width * r->height * sizeof(float4), r->stream));
     HIP_TRY(hipStreamSynchronize(r->stream));      // frames on the other streams must not overtake the clear
+    return 0;
+}
+
+int rtx_get_info(RtxRenderer* r, RtxInfo* out) {
+    if (!r || !out) return fail("NULL argument");
+    *out = r->info;
     return 0;
 }
 

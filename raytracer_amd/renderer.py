@@ -11,11 +11,11 @@ import ctypes as C
 import numpy as np
 
 from . import _capi
-from ._capi import Camera, Config, Counters, SceneDesc
+from ._capi import Camera, Config, Counters, Info, SceneDesc
 
 
 class HIPShader:
-    def __init__(self, scene, device=0, rank=0, world_size=1, tile=(64, 32), traversal=_capi.TRAVERSE_CULLED,
+    def __init__(self, scene, device=0, rank=0, world_size=1, tile=(64, 32), traversal=_capi.TRAVERSE_WIDE,
                  count_stats=False, frames_in_flight=0):
         """`scene` is a raytracer_amd.scene.HostScene (or anything with .desc() and
         .camera); its arrays are read once, here (as src/CLShader.cpp:20-49 does)."""
@@ -100,6 +100,12 @@ class HIPShader:
         c = Counters()
         self._chk(self._L.rtx_get_counters(self._h, C.byref(c)), "rtx_get_counters")
         return c
+
+    def info(self):
+        """What rtx_create decided: traversal in effect, culling slack, frames in flight, tree sizes (RtxInfo)."""
+        i = Info()
+        self._chk(self._L.rtx_get_info(self._h, C.byref(i)), "rtx_get_info")
+        return i
 
     def reset_counters(self):
         self._chk(self._L.rtx_reset_counters(self._h), "rtx_reset_counters")

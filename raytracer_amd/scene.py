@@ -98,6 +98,13 @@ class HostScene:
                                                      float(amplitude), float(tilt_deg), float(center[0]),
                                                      float(center[1]), float(center[2]), m.ctypes.data, len(m)))
 
+    def write_heightfield_obj(self, path, ntri, seed, extent_u, extent_v, amplitude, tilt_deg, center, material_ids):
+        """The mesh add_heightfield would add, as OBJ text (materials referenced by name through usemtl)."""
+        m = np.ascontiguousarray(material_ids, dtype=np.int32)
+        self._chk(self._L.rtxh_write_heightfield_obj(self._h, os.fsencode(path), int(ntri), int(seed), float(extent_u),
+                                                     float(extent_v), float(amplitude), float(tilt_deg), float(center[0]),
+                                                     float(center[1]), float(center[2]), m.ctypes.data, len(m)))
+
     def build_bvh(self, nthreads=8):
         self._chk(self._L.rtxh_scene_build_bvh(self._h, int(nthreads)))
         return self
@@ -237,11 +244,16 @@ def procedural_texture(size, seed):
     return (r | (g << np.uint32(8)) | (b << np.uint32(16)) | np.uint32(255 << 24)).astype(np.uint32)
 
 
-def synthetic_scene(ntri, width, height, seed=12345, textured=True, tex_size=1024, nthreads=8, bvh=True):
+def synthetic_scene(ntri, width, height, seed=12345, textured=True, tex_size=1024, nthreads=8, bvh=True, via_obj=None, grid=None):
     """Floor plane + disk light (as resources/scenes/2.scn) + a seeded height-field
     mesh of exactly `ntri` triangles that fills the default camera's view
     (SURVEY.md §8d). Texture 1 (hard-wired as the sky, src/ThreadedShader.cpp:162)
-    is a procedural sky texture."""
+    is a procedural sky texture.
+    via_obj: path of an OBJ text file to write the mesh to and load it back from (the reference's own mesh route,
+    src/MeshSerializer.cpp:141-243; BASELINE.json configs[2] "1 M-tri OBJ") instead of filling the objects directly.
+    grid = (nx, ny): the mesh is the base mesh of ntri // (nx*ny) triangles replicated on an nx x ny grid of
+    explicit copies (BASELINE.json configs[4]: a 1 M-triangle base mesh x 100; the reference has no instancing,
+    SURVEY.md H6)."""
     s = HostScene(width, height)
     w, h = s.width, s.height
     sky = s.add_texture(procedural_texture(tex_size, 1))
@@ -267,7 +279,22 @@ def synthetic_scene(ntri, width, height, seed=12345, textured=True, tex_size=102
     half_h = 0.41421356 * (900 + 240)
     half_w = half_h * float(aspect)
     cx, cy, cz = (500 - w / 2.0) / scale, (560 - h / 2.0) / scale, 0.0
-    s.add_heightfield(ntri, seed, 2.1 * half_w / scale, 2.1 * half_h / scale, 60.0 / scale, 25.0, (cx, cy, cz), mats)
+    hf = (seed, 2.1 * half_w / scale, 2.1 * half_h / scale, 60.0 / scale, 25.0)
+    if grid is not None:
+        nx, ny = grid
+        base = ntri // (nx * ny)
+        assert base * nx * ny == ntri
+        # copies side by side, each 1/nx x 1/ny of the extent: same footprint as the single mesh, one seed per copy
+        for j in range(ny):
+            for i in range(nx):
+                c = (cx + ((i + 0.5) / nx - 0.5) * hf[1], cy + ((j + 0.5) / ny - 0.5) * hf[2] * float(np.cos(np.radians(25.0))),
+                     cz + ((j + 0.5) / ny - 0.5) * hf[2] * float(np.sin(np.radians(25.0))))
+                s.add_heightfield(base, seed, hf[1] / nx, hf[2] / ny, hf[3] / max(nx, ny), hf[4], c, mats)
+    elif via_obj is not None:
+        s.write_heightfield_obj(via_obj, ntri, *hf, (cx, cy, cz), mats)
+        s.load_obj(via_obj)
+    else:
+        s.add_heightfield(ntri, *hf, (cx, cy, cz), mats)
     if bvh:
         s.build_bvh(nthreads)
     return s

@@ -86,7 +86,8 @@ def test_sliver_scene_is_not_culled_by_distance(libs):
     d, cam = s.desc(), s.camera
     rng = np.random.default_rng(5038)
     o0, d0 = oracle.primary_rays(d, cam, 0)
-    rc = HIPShader(s)
+    rc = HIPShader(s, traversal=_capi.TRAVERSE_CULLED)
+    assert np.isinf(rc.info().cullSlack) and rc.info().sliverFraction > 1e-3 and rc.info().traversal == _capi.TRAVERSE_WIDE
     re = HIPShader(s, traversal=_capi.TRAVERSE_EXACT)
     ids, pts, nrm = re.trace_rays(o0, d0)
     hit = ids >= 0

@@ -228,3 +228,32 @@ def test_bundled_scene_counts():
     assert (len(s.objects), len(s.boxes), len(s.materials)) == (226, 451, 14)
     assert (s.objects["type"] == _capi.TRIANGLE).all()
     assert s.texture_info["width"][1] == 1024        # first texture that loads becomes the sky (copper.bmp)
+
+
+def test_obj_route_equals_direct_fill(libs, tmp_path):
+    """SURVEY.md H6 / BASELINE.json configs[2] ("1 M-tri OBJ"): the mesh written as OBJ text and read back through the
+    MeshSerializer-equivalent loader (src/MeshSerializer.cpp:96-137,141-243: atof, usemtl by name, f a//a b//b c//c,
+    v*100*aspect + (w/2,h/2,depth/2), position = centroid) gives byte-identical objects — and therefore the identical
+    BVH — to the direct fill the large configurations use. (tests/test_gpu_configs.py repeats this at 1 M triangles.)"""
+    a = synthetic_scene(60_000, 640, 360, seed=99, tex_size=16, nthreads=4)
+    obj = str(tmp_path / "mesh.obj")
+    b = synthetic_scene(60_000, 640, 360, seed=99, tex_size=16, nthreads=4, via_obj=obj)
+    text = open(obj).read(4096)
+    assert text.startswith("# synthetic") and "\nv " in text
+    assert sum(1 for line in open(obj) if line.startswith("f ")) == 60_000
+    assert sum(1 for line in open(obj) if line.startswith("usemtl ")) > 1
+    assert a.objects.tobytes() == b.objects.tobytes()
+    assert a.boxes.tobytes() == b.boxes.tobytes()
+    assert a.materials.tobytes() == b.materials.tobytes()
+
+
+def test_grid_replication_makes_explicit_copies(libs):
+    """BASELINE.json configs[4]: a base mesh replicated on a grid into explicit triangles (no instancing in the reference)."""
+    s = synthetic_scene(40_000, 640, 360, seed=5, tex_size=16, nthreads=4, grid=(5, 4))
+    assert len(s.objects) == 40_000 + 32 + 2 and len(s.boxes) == 2 * len(s.objects) - 1
+    tri = s.objects[34:]
+    per = 2_000
+    # every copy is the base mesh translated: same edge vectors up to rounding of the translation, different positions
+    e0 = tri["vertices"][:per, 1, :3] - tri["vertices"][:per, 0, :3]
+    e1 = tri["vertices"][per:2 * per, 1, :3] - tri["vertices"][per:2 * per, 0, :3]
+    assert np.allclose(e0, e1, atol=1e-2) and not np.allclose(tri["position"][:per], tri["position"][per:2 * per])
