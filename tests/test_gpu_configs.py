@@ -104,13 +104,18 @@ def test_cfg3_obj_route_1m_triangles_1080p(libs, tmp_path):
     check_fb(out["wide"][1][y0:y1], want[y0:y1])
 
 
-# Triangles of the orbit test. BASELINE.json configs[4] names 100 M; that needs ~40 GB of host arrays and minutes of host
-# time, so the default is the same shape at 10 M (with the 64-bit node addressing a 100 M tree uses forced on), and
-# RTX_TEST_ORBIT_TRIS=100000000 runs the real size (scripts/gpu_cfg5_full.sh; result recorded in DESIGN.md section 5).
-ORBIT_TRIS = int(os.environ.get("RTX_TEST_ORBIT_TRIS", "10000000"))
+def _orbit_sizes():
+    """BASELINE.json configs[4] names 100 M triangles: ~40 GB of host arrays (256-byte objects + 64-byte boxes), ~35 GB
+    on the device, about a minute on the GPU box. It runs when the host has the memory for it; the 10 M case (with the
+    64-bit node addressing a 100 M tree needs forced on) always runs."""
+    import psutil
+    enough = psutil.virtual_memory().available > 110 * 2**30
+    return [10_000_000, pytest.param(100_000_000, marks=pytest.mark.skipif(
+        not enough or os.environ.get("RTX_TEST_SKIP_100M") == "1", reason="needs ~110 GiB of free host memory"))]
 
 
-def test_cfg5_orbit_camera_over_a_replicated_mesh_4k(libs, monkeypatch):
+@pytest.mark.parametrize("ORBIT_TRIS", _orbit_sizes())
+def test_cfg5_orbit_camera_over_a_replicated_mesh_4k(libs, monkeypatch, ORBIT_TRIS):
     """BASELINE.json configs[4] shape: base mesh x 100 explicit copies (10x10 grid), -O orbit loop: every frame a new
     camera on the circle of src/Main.cpp:68-77 (radius 5000, yaw/pitch += 0.1 deg per frame, LookAt(0,0,0)) and
     frameCounter = 0, i.e. the same seeds and a Lerp scale of 1: each frame overwrites the last. Frames are queued
