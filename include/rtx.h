@@ -225,6 +225,17 @@ int rtx_primary_hits(RtxRenderer* r, const RtxCamera* camera, uint32_t frameCoun
 int rtx_trace_rays(RtxRenderer* r, const float* origins, const float* directions, uint64_t n,
                    int32_t* objectIDs, float* points, float* normals);
 
+/* rtx_trace_rays for callers that cannot allocate. NO COUNTERPART IN THE REFERENCE: it exists for code under HIP graph
+ * capture, tight serving loops and harnesses that forbid hipMalloc. Same kernels and results as rtx_trace_rays, but
+ * origins / directions / outputs are DEVICE pointers (n*4 floats, n ints, n*4, n*4; each output may be NULL) and the
+ * intermediate buffers rtx_trace_rays allocates per call (work counters, hit distances, hit leaves, side list, staged
+ * directions) live in one fixed file-scope device array of 14 MiB per GPU, held until the process ends. The call
+ * issues no hipMalloc / hipFree (device or pinned) and returns after the results are complete.
+ * Limits: n <= 524288 rays per call (a larger n is rejected with an error; split the batch). Every call on a GPU
+ * shares that GPU's array, so calls that overlap on one GPU — from several threads or renderers — race: serialise them. */
+int rtx_trace_rays_noalloc(RtxRenderer* r, const float* d_origins, const float* d_directions, uint64_t n,
+                           int32_t* d_objectIDs, float* d_points, float* d_normals);
+
 /* Overwrite / read the resident running-mean framebuffer (the reference's
  * `pixels`, src/WindowManager.cpp:26-27). */
 int rtx_upload_pixels(RtxRenderer* r, const float* pixels_rgba);

@@ -141,6 +141,7 @@ def hip_lib():
         L.rtx_render.argtypes = [C.c_void_p, C.POINTER(Camera), C.c_uint32, C.c_void_p]
         L.rtx_primary_hits.argtypes = [C.c_void_p, C.POINTER(Camera), C.c_uint32, C.c_void_p]
         L.rtx_trace_rays.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.rtx_trace_rays_noalloc.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
         for fn in ("rtx_upload_pixels", "rtx_download_pixels"):
             getattr(L, fn).argtypes = [C.c_void_p, C.c_void_p]
         L.rtx_clear_pixels.argtypes = [C.c_void_p]
@@ -167,7 +168,7 @@ def hip_lib():
     return _hip
 
 
-EXPORTED_HIP = ["rtx_create", "rtx_render", "rtx_primary_hits", "rtx_trace_rays", "rtx_upload_pixels",
+EXPORTED_HIP = ["rtx_create", "rtx_render", "rtx_primary_hits", "rtx_trace_rays", "rtx_trace_rays_noalloc", "rtx_upload_pixels",
                 "rtx_download_pixels", "rtx_clear_pixels", "rtx_get_info", "rtx_get_counters", "rtx_reset_counters", "rtx_destroy",
                 "rtx_last_error", "rtx_framebuffer_device_ptr", "rtx_stream", "rtx_local_pixel_count",
                 "rtx_local_tile_count", "rtx_packed_floats", "rtx_pack_tiles", "rtx_unpack_tiles", "rtx_version"]

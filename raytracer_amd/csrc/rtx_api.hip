@@ -29,6 +29,19 @@ static int fail(const std::string& m) { g_err = m; return 1; }
         if (e_ != hipSuccess) return fail(std::string(#expr) + ": " + hipGetErrorString(e_)); \
     } while (0)
 
+// ---- scratch of rtx_trace_rays_noalloc --------------------------------------------------------------------------
+// One file-scope device array per GPU (every device that loads this code object holds its own copy at its own
+// address, until the process ends): work counters, hit distances, hit leaves, the list of rays for the
+// reference-topology side kernel, and the staged directions of up to RTX_NOALLOC_MAX_RAYS rays. In host code the
+// array's NAME is only a handle for hipGetSymbolAddress; kernels and memsets get the per-device address g_scratch[dev].
+#define RTX_NOALLOC_MAX_RAYS (1u << 19)
+#define RTX_NOALLOC_CTRL_BYTES ((RTX_CTRL_WORDS * 4u + 255u) & ~255u)
+#define RTX_NOALLOC_BYTES (RTX_NOALLOC_CTRL_BYTES + (size_t)RTX_NOALLOC_MAX_RAYS * (4u + 4u + 4u + 16u))     // 14.0 MiB + 8.25 KiB
+static __device__ __align__(256) unsigned char scratch[RTX_NOALLOC_BYTES];
+static const int kMaxDevices = 64;
+static unsigned char* g_scratch[kMaxDevices] = {};      // per device: address of that device's copy of scratch[]
+static std::mutex g_scratchMutex;
+
 static const int kRing = 32;      // frames whose timing events are kept; a frame's timing is read kLag frames later
 static const int kLag = 16;
 static const int kEvents = 10;    // start + one per kernel (8) + end
@@ -665,6 +678,15 @@ int rtx_create(const RtxSceneDesc* scene, const RtxConfig* cfgIn, RtxRenderer** 
     hipDeviceProp_t prop;
     CREATE_HIP(hipGetDeviceProperties(&prop, r->device));
     r->numCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (r->device < 0 || r->device >= kMaxDevices) { fail("device ordinal out of range"); rtx_destroy(r); return 1; }
+    {   // once per device, with that device current: where this device keeps its copy of scratch[]
+        std::lock_guard<std::mutex> g(g_scratchMutex);
+        if (!g_scratch[r->device]) {
+            unsigned char* ptr = nullptr;
+            CREATE_HIP(hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch)));
+            g_scratch[r->device] = ptr;
+        }
+    }
     size_t freeBefore = 0, freeAfter = 0, totalMem = 0;
     CREATE_HIP(hipMemGetInfo(&freeBefore, &totalMem));
     for (int i = 0; i < kRing; ++i) for (int k = 0; k < kEvents; ++k) CREATE_HIP(hipEventCreate(&r->ev[i][k]));
@@ -1038,6 +1060,40 @@ int rtx_trace_rays(RtxRenderer* r, const float* origins, const float* directions
     void* ptrs[] = {dO, dD, dP, dN, dT, dL, dI, dSlowTmp};
     for (void* p : ptrs) if (p) hipFree(p);
     if (e != hipSuccess) return fail(std::string("rtx_trace_rays: ") + hipGetErrorString(e));
+    return 0;
+}
+
+// See include/rtx.h. Same kernels and launch sequence as rtx_trace_rays; what that call allocates per call (hit
+// distances, hit leaves, side list, staged directions) and the work counters live in this device's scratch[] instead.
+int rtx_trace_rays_noalloc(RtxRenderer* r, const float* d_origins, const float* d_directions, uint64_t n,
+                           int32_t* d_objectIDs, float* d_points, float* d_normals) {
+    if (!r || !d_origins || !d_directions) return fail("NULL argument");
+    if (n == 0) return 0;
+    if (n > RTX_NOALLOC_MAX_RAYS)
+        return fail("rtx_trace_rays_noalloc: " + std::to_string(n) + " rays exceed the fixed scratch of " + std::to_string(RTX_NOALLOC_MAX_RAYS) +
+                    " rays per call (split the batch, or use rtx_trace_rays)");
+    HIP_TRY(hipSetDevice(r->device));
+    unsigned char* base = g_scratch[r->device];          // set in rtx_create on this device
+    if (!base) return fail("rtx_trace_rays_noalloc: scratch address of this device is unknown");
+    if (sync_all(r)) return 1;
+    uint32_t* sCtrl = (uint32_t*)base;
+    float* sT = (float*)(base + RTX_NOALLOC_CTRL_BYTES);
+    int* sL = (int*)(sT + RTX_NOALLOC_MAX_RAYS);
+    uint32_t* sSlow = (uint32_t*)(sL + RTX_NOALLOC_MAX_RAYS);
+    float4* sD = (float4*)(sSlow + RTX_NOALLOC_MAX_RAYS);
+    const uint32_t cnt = (uint32_t)n;
+    // the array keeps the last call's contents: the counters must start at zero, the queue length is this call's
+    HIP_TRY(hipMemsetAsync(sCtrl, 0, RTX_CTRL_WORDS * sizeof(uint32_t), r->stream));
+    hipLaunchKernelGGL(k_stage_directions, dim3((cnt + 255u) / 256u), dim3(256), 0, r->stream, (const float4*)d_directions, sD, cnt);
+    float* saveT = r->dHitT; int* saveL = r->dHitLeaf; uint32_t* saveS = r->dSlow; uint32_t* saveC = r->dCtrl;
+    r->dHitT = sT; r->dHitLeaf = sL; r->dSlow = sSlow; r->dCtrl = sCtrl;
+    set_grids(r, cnt);
+    dispatch_trace(r, (const float4*)d_origins, sD, 0, 0, cnt);        // countIdx 0: the queue length travels as an argument
+    r->dHitT = saveT; r->dHitLeaf = saveL; r->dSlow = saveS; r->dCtrl = saveC;
+    hipLaunchKernelGGL(k_probe_finish, dim3((cnt + 255u) / 256u), dim3(256), 0, r->stream, r->sc, r->linear ? 1 : 0,
+                       (const float4*)d_origins, sD, sT, sL, cnt, d_objectIDs, (float4*)d_points, (float4*)d_normals);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(r->stream));           // the next call on this GPU reuses the array
     return 0;
 }
 

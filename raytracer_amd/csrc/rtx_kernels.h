@@ -544,9 +544,17 @@ __global__ void k_probe_finish(DevScene sc, int linearMode, const float4* __rest
         point = add4(o, mul4(dirForPoint, hitT[q]));
         normal = hit_normal(prim, point);
     }
-    ids[q] = id;
-    points[q] = make_float4(point.x, point.y, point.z, 0.0f);
-    normals[q] = make_float4(normal.x, normal.y, normal.z, 0.0f);
+    if (ids) ids[q] = id;
+    if (points) points[q] = make_float4(point.x, point.y, point.z, 0.0f);
+    if (normals) normals[q] = make_float4(normal.x, normal.y, normal.z, 0.0f);
+}
+
+// rtx_trace_rays_noalloc: the caller's directions (4th lane "ignored") -> queue entries (4th lane 0 = a ray)
+__global__ void k_stage_directions(const float4* __restrict__ in, float4* __restrict__ out, uint32_t n) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n) return;
+    const float4 d = in[q];
+    out[q] = make_float4(d.x, d.y, d.z, 0.0f);
 }
 
 // ---- multi-GPU tile plumbing ----------------------------------------------------
