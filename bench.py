@@ -9,17 +9,30 @@ A step = one frame = one sample per pixel over the whole image (the reference's
 "N spp" is N accumulated frames). Default workload = BASELINE.json
 configs[3] shape: synthetic 10 M-triangle mesh + textured materials, 3840x2160
 (rendered at 3840x2176 after the reference's rounding to multiples of 32), scene
-replicated on every GPU, screen tiles dealt round-robin to the ranks, tiles
-gathered to rank 0 once at the end of the timed batch (RCCL). Total work is the
-same for every N (strong scaling). The frame stays resident in HBM; the optional
-device-to-host copy is reported separately (--d2h), never inside `value`.
+replicated on every GPU, screen tiles dealt round-robin to the ranks. Total work is
+the same for every N (strong scaling).
+
+What `value` is: rays traced by all ranks / wall time of { K x rtx_render(pixels = NULL) in the library's DEFAULT
+traversal mode (RTX_TRAVERSE_WIDE: the reference's result by construction) ; gather of the tiles to rank 0 (RCCL) ;
+one device-to-host copy of the finished frame } — the delivered-batch pattern of BASELINE.json configs[3] (64 spp,
+one image). Scene and running mean are resident in HBM when the clock starts. Printed beside it, as top-level keys
+of the same line:
+  sync_boundary   the reference's own calling pattern — Render(pixels) synchronously every frame, each frame copied
+                  to the host (src/WindowManager.cpp:154-158) — measured in a child process that leaves
+                  GPU_MAX_HW_QUEUES at HIP's default (PCIe-inclusive; never `value`)
+  culled_opt_in   the same frames with distance culling (RTX_TRAVERSE_CULLED, opt-in, not exact by construction)
+  roofline        dominant kernel: algorithmic bytes (SURVEY.md §8d constants x device-counted visits) over its HIP-event
+                  duration, HBM traffic from the committed rocprofv3 PMC pass if it belongs to this very kernel source
+  cpu_baseline    the oracle (CPU restatement of ThreadedShader, static row bands) on a bounded sample, strict and -Ofast
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import ctypes as C
+import hashlib
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -27,19 +40,55 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
-# frames are queued several deep, one stream each: give the process a hardware queue per stream
-# (HIP reads this once, when the process first touches the GPU; the usual value is 4)
-if int(os.environ.get("GPU_MAX_HW_QUEUES", "4")) < 16:
-    os.environ["GPU_MAX_HW_QUEUES"] = "16"
 
 WORKLOADS = {
-    # name: (triangles, width, height, textured)
-    "cfg4_10Mtri_4k": (10_000_000, 3840, 2160, True),
-    "cfg3_1Mtri_1080p": (1_000_000, 1920, 1080, False),
-    "cfg5_100Mtri_4k": (100_000_000, 3840, 2160, True),
-    "small_100ktri_992": (100_000, 1000, 1000, True),
+    # name: (triangles, width, height, textured, grid)
+    "cfg4_10Mtri_4k": (10_000_000, 3840, 2160, True, None),
+    "cfg3_1Mtri_1080p": (1_000_000, 1920, 1080, False, None),
+    "cfg5_100Mtri_4k": (100_000_000, 3840, 2160, True, (10, 10)),
+    "small_100ktri_992": (100_000, 1000, 1000, True, None),
 }
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+
+
+def csrc_digest():
+    """Identity of the kernel source the committed PMC numbers were taken with."""
+    h = hashlib.sha256()
+    d = os.path.join(HERE, "raytracer_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".h", ".hip")):
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def sync_only(args):
+    """Child process: the reference's calling pattern. Render(pixels) per frame, synchronous, frame copied to the host
+    every time, whatever GPU_MAX_HW_QUEUES the environment has (HIP's default 4 when the parent removed it)."""
+    from raytracer_amd import _capi
+    from raytracer_amd.renderer import HIPShader
+    from raytracer_amd.scene import synthetic_scene
+    ntri, w, h, textured, grid = WORKLOADS[args.workload]
+    scene = synthetic_scene(ntri, w, h, seed=12345, textured=textured, nthreads=16, grid=grid)
+    shader = HIPShader(scene, device=0, traversal={"wide": _capi.TRAVERSE_WIDE, "culled": _capi.TRAVERSE_CULLED, "exact": _capi.TRAVERSE_EXACT}[args.traversal])
+    px = np.zeros((shader.height, shader.width, 4), dtype=np.float32)
+    for i in range(2):
+        shader.frame_counter = i
+        shader.Render(px)
+    shader.reset_counters()
+    n = max(4, min(args.steps, 32))
+    t0 = time.perf_counter()
+    for i in range(n):
+        shader.frame_counter = 2 + i            # src/WindowManager.cpp:156-157
+        shader.Render(px)
+    dt = time.perf_counter() - t0
+    c = shader.counters()
+    info = shader.info()
+    print(json.dumps({"ms_per_step": dt / n * 1e3, "mrays_per_s": float(c.rays) / dt / 1e6, "frames": n,
+                      "device_ms_per_frame": c.totalMs / max(1, c.frames),
+                      "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"), "hw_queues_seen": info.hwQueues,
+                      "pattern": "rtx_render(pixels) per frame, synchronous, 16 B/pixel copied to a pageable host array every frame"}))
+    shader.close()
 
 
 def main():
@@ -48,15 +97,24 @@ def main():
     ap.add_argument("--steps", type=int, default=64)
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--workload", default="cfg4_10Mtri_4k", choices=sorted(WORKLOADS))
-    ap.add_argument("--traversal", default="culled", choices=["culled", "exact", "wide"])
+    ap.add_argument("--traversal", default="wide", choices=["wide", "culled", "exact"],
+                    help="wide = the library default (the reference's result by construction)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-extras", action="store_true", help="skip the sync_boundary / culled_opt_in legs (profiling runs)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--frames-in-flight", type=int, default=0,
-                    help="RtxConfig.framesInFlight for the timed region: 0 = library default (14 with the 16 hardware queues set above), "
+                    help="RtxConfig.framesInFlight for the timed region: 0 = library default for the process' hardware queues, "
                          "1 = strictly serial frames")
-    ap.add_argument("--d2h", action="store_true", help="also time K frames with the host copy (reported in `extra`)")
     ap.add_argument("--orbit", action="store_true", help="-O camera: new camera + frameCounter=0 every frame (src/Main.cpp:68-82)")
+    ap.add_argument("--sync-only", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.sync_only:
+        return sync_only(args)
+
+    # frames are queued several deep, one stream each: give the process a hardware queue per stream
+    # (HIP reads this once, when the process first touches the GPU; its default is 4)
+    if int(os.environ.get("GPU_MAX_HW_QUEUES", "4")) < 16:
+        os.environ["GPU_MAX_HW_QUEUES"] = "16"
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -89,47 +147,54 @@ def main():
     from raytracer_amd.renderer import HIPShader
     from raytracer_amd.scene import orbit as orbit_camera, synthetic_scene
 
-    ntri, w, h, textured = WORKLOADS[args.workload]
+    ntri, w, h, textured, grid = WORKLOADS[args.workload]
     cores = max(1, min(16, os.cpu_count() or 1))
     t0 = time.time()
-    scene = synthetic_scene(ntri, w, h, seed=12345, textured=textured, nthreads=cores)
+    scene = synthetic_scene(ntri, w, h, seed=12345, textured=textured, nthreads=cores, grid=grid)
     t_scene = time.time() - t0
-    trav = {"culled": _capi.TRAVERSE_CULLED, "exact": _capi.TRAVERSE_EXACT, "wide": _capi.TRAVERSE_WIDE}[args.traversal]
+    modes = {"wide": _capi.TRAVERSE_WIDE, "culled": _capi.TRAVERSE_CULLED, "exact": _capi.TRAVERSE_EXACT}
+    trav = modes[args.traversal]
     t0 = time.time()
     shader = HIPShader(scene, device=local_rank, rank=rank, world_size=world, traversal=trav,
                        frames_in_flight=args.frames_in_flight)
     t_create = time.time() - t0
+    info = shader.info()
     W, H = shader.width, shader.height
     gather = DeviceGather(shader, rank, world, torch.device("cuda", local_rank), host_staging=backend != "nccl") if use_dist else None
     cam = scene.camera
+    frame = np.zeros((H, W, 4), dtype=np.float32) if rank == 0 else None
 
-    def step(i):
+    def step(sh, i):
         if args.orbit:
             orbit_camera(cam, 0.1 * i, 0.1 * i)
-            shader.frame_counter = 0
-            shader.Render(None, cam)
+            sh.frame_counter = 0
         else:
-            shader.frame_counter = i
-            shader.Render(None, cam)
+            sh.frame_counter = i
+        sh.Render(None, cam)
+
+    def deliver():
+        """The batch's one exchange and one copy: tiles to rank 0 (RCCL), finished frame to the host."""
+        if gather is not None:
+            gather.gather()
+        if rank == 0:
+            shader.download_into(frame)
 
     def barrier():
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
-        shader.counters()            # synchronises the renderer's own stream
+        shader.counters()            # synchronises the renderer's own streams
 
     for i in range(args.warmup):
-        step(i)
-    if gather is not None:
-        gather.gather()
+        step(shader, i)
+    deliver()
     barrier()
     shader.reset_counters()
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        step(args.warmup + i)
-    if gather is not None:
-        gather.gather()                # one exchange per delivered frame batch
+        step(shader, args.warmup + i)
+    deliver()
     c = shader.counters()              # stream sync
     torch.cuda.synchronize()
     if use_dist:
@@ -145,24 +210,15 @@ def main():
     elapsed = float(t.item())
     rays = float(rsum.item())
     kernel_ms = [x / max(1, c.frames) for x in c.kernelMs]
-    rays_per_bounce = [int(x) for x in c.raysPerBounce]
-    hits_per_bounce = [int(x) for x in c.hitsPerBounce]
+    names8 = ["primary", "shade0", "trace1", "shade1", "trace2", "shade2", "trace3", "shade3"]
 
     extra = {"scene_build_s": round(t_scene, 2), "rtx_create_s": round(t_create, 2),
-             "overlapped_kernel_ms_per_frame": {"primary": kernel_ms[0], "shade0": kernel_ms[1], "trace1": kernel_ms[2],
-                                     "shade1": kernel_ms[3], "trace2": kernel_ms[4], "shade2": kernel_ms[5],
-                                     "trace3": kernel_ms[6], "shade3": kernel_ms[7]},
+             "rtx_create_phases_s": {"validate_walk": info.createSeconds[0], "own_tree": info.createSeconds[1],
+                                     "records": info.createSeconds[2], "upload_alloc": info.createSeconds[3]},
+             "device_bytes": int(info.deviceBytes), "wide_nodes": int(info.wideNodes), "wide_tree_depth": info.wideTreeDepth,
+             "overlapped_kernel_ms_per_frame": dict(zip(names8, kernel_ms)),
              "device_ms_per_frame": c.totalMs / max(1, c.frames),
-             "rays_per_bounce_rank0": rays_per_bounce, "hits_per_bounce_rank0": hits_per_bounce}
-
-    if args.d2h and rank == 0:
-        px = np.zeros((H, W, 4), dtype=np.float32)
-        shader.Render(px, cam)
-        t1 = time.perf_counter()
-        for i in range(args.steps):
-            shader.frame_counter = args.warmup + args.steps + i
-            shader.Render(px, cam)
-        extra["ms_per_frame_with_d2h"] = (time.perf_counter() - t1) / args.steps * 1e3
+             "rays_per_bounce_rank0": [int(x) for x in c.raysPerBounce], "hits_per_bounce_rank0": [int(x) for x in c.hitsPerBounce]}
 
     # ---- roofline of the dominant kernel (rank 0) ---------------------------------------------------------
     # The timed region keeps several frames in flight, so a launch there shares the machine with launches of
@@ -174,17 +230,10 @@ def main():
         shader.close()
         counter = HIPShader(scene, device=local_rank, rank=rank, world_size=world, traversal=trav, count_stats=True,
                             frames_in_flight=1)
-        def count_step(i):
-            if args.orbit:
-                orbit_camera(cam, 0.1 * i, 0.1 * i)
-                counter.frame_counter = 0
-            else:
-                counter.frame_counter = i
-            counter.Render(None, cam)
-        count_step(0)
+        step(counter, 0)
         counter.reset_counters()
         for i in range(args.steps):
-            count_step(args.warmup + i)
+            step(counter, args.warmup + i)
         cc = counter.counters()
         counter.close()
         serial_ms = [x / max(1, cc.frames) for x in cc.kernelMs]
@@ -192,64 +241,68 @@ def main():
         b = int(np.argmax(trace_ms))
         inner = cc.innerVisits[b] / args.steps
         leaf = cc.leafTests[b] / args.steps
-        # bytes a traversal step reads: culled path = one 4-wide node, 7 x 16 B (6 plane vectors + 4 refs);
-        # exact path = one binary node of the reference topology, 64 B; a leaf test reads 48 B
-        node_bytes = 112.0 if args.traversal in ("culled", "wide") else 64.0
-        requested_bytes = node_bytes * inner + 48.0 * leaf
+        # bytes the loads of a step request: quantised 4-wide node 48 B (3 x 16) and 64-B leaf record (wide);
+        # 4-wide float node 112 B (7 x 16) and 40 B of the leaf record (culled); binary node 64 B + 40 B (exact)
+        node_bytes, leaf_bytes, node_loads, leaf_loads = {"wide": (48.0, 64.0, 3.0, 4.0), "culled": (112.0, 40.0, 7.0, 3.0),
+                                                          "exact": (64.0, 40.0, 4.0, 3.0)}[args.traversal]
         # headline `achieved` keeps SURVEY.md §8d's constants (64 B per node step, 48 B per leaf test) whatever the
-        # node width, so that rounds stay comparable; the bytes the loads really request are reported beside it
+        # node format, so that rounds stay comparable; the bytes the loads really request are reported beside it
         algo_bytes = 64.0 * inner + 48.0 * leaf
         achieved = algo_bytes / (trace_ms[b] * 1e-3) / 1e9 if trace_ms[b] > 0 else 0.0
-        traffic, tcp_accesses = None, None
+        kname = ["k_primary", "k_trace1", "k_trace2", "k_trace3"][b]
+        traffic, tcp_accesses, traffic_source = None, None, None
+        digest = csrc_digest()
         pmc = os.path.join(HERE, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
             try:
                 pj = json.load(open(pmc))
-                kname = ["k_primary", "k_trace1", "k_trace2", "k_trace3"][b]
-                traffic = pj.get(args.workload, {}).get(kname)
-                tcp_accesses = pj.get(args.workload + ":tcp_accesses", {}).get(kname)
-            except Exception:
-                traffic, tcp_accesses = None, None
+                key = f"{args.workload}:{args.traversal}"
+                if pj.get("csrc_sha256_16") == digest and key in pj and not args.orbit:
+                    traffic = pj[key].get(kname)
+                    tcp_accesses = pj.get(key + ":tcp_accesses", {}).get(kname)
+                    traffic_source = f"profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel source, csrc {digest})"
+                else:
+                    traffic_source = (f"not emitted: profiles/pmc_traffic.json was taken with csrc {pj.get('csrc_sha256_16')} "
+                                      f"for {sorted(k for k in pj if ':' in k and not k.endswith('tcp_accesses'))}, this run is csrc {digest} {key}")
+            except Exception as e:          # a malformed file must not cost the bench line
+                traffic_source = f"not emitted: {e}"
         all_rays = sum(cc.raysPerBounce)
-        # What actually stops this launch is not HBM but the rate at which a CU's vector L1 accepts 16-byte lane
-        # loads (tools/tcp_rate, profiles/r01_tcp_rate.txt: 0.87 per clock per CU for this access pattern):
-        # a node step of the culled path is 7 such loads per lane, a leaf test 3.
         props = torch.cuda.get_device_properties(local_rank)
         clock_hz = float(getattr(props, "clock_rate", 2400000)) * 1e3
-        lane_loads = (7.0 if args.traversal in ("culled", "wide") else 4.0) * inner + 3.0 * leaf
+        lane_loads = node_loads * inner + leaf_loads * leaf
         cu_clocks = trace_ms[b] * 1e-3 * clock_hz * props.multi_processor_count
-        l1 = {"lane_loads_issued_per_launch": lane_loads,                  # 7 I' + 3 L' from the device counters
-              # what the L1 counted for this launch (TCP_TOTAL_CACHE_ACCESSES, profiles/pmc_traffic.json): lanes of a
-              # wave that read the same address — the top of the tree — arrive merged, so this is below `issued`
-              "l1_accesses_per_launch_pmc": tcp_accesses,
-              "per_clock_per_cu": (tcp_accesses / cu_clocks) if (tcp_accesses and cu_clocks > 0) else None,
-              "issued_per_clock_per_cu": lane_loads / cu_clocks if cu_clocks > 0 else None,
-              "ceiling_per_clock_per_cu": 0.87, "ceiling_source": "tools/tcp_rate mode 2 (7 loads per scattered line, L2-resident)",
-              "clock_hz": clock_hz, "cus": props.multi_processor_count}
-        names = (["k_primary<CULLED, count>", "k_trace_refill<count, 1>", "k_trace_refill<count, 2>", "k_trace_refill<count, 3>"]
-                 if args.traversal in ("culled", "wide") else ["k_primary<EXACT, count>", "k_trace<EXACT, count> bounce 1",
-                                                     "k_trace<EXACT, count> bounce 2", "k_trace<EXACT, count> bounce 3"])
-        roofline = {"bound": "hbm", "kernel": names[b],
+        kernels = {"wide": ["k_primary<WIDEQ, count>", "k_trace_q<count, 1>", "k_trace_q<count, 2>", "k_trace_q<count, 3>"],
+                   "culled": ["k_primary<CULLED, count>", "k_trace_refill<count, 1>", "k_trace_refill<count, 2>", "k_trace_refill<count, 3>"],
+                   "exact": ["k_primary<EXACT, count>", "k_trace<EXACT, count> bounce 1", "k_trace<EXACT, count> bounce 2",
+                             "k_trace<EXACT, count> bounce 3"]}[args.traversal]
+        roofline = {"bound": "hbm", "kernel": kernels[b],
                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                    "traffic": traffic,
+                    "traffic": traffic, "traffic_source": traffic_source,
+                    "hbm_traffic_gbs": (traffic / (trace_ms[b] * 1e-3) / 1e9) if (traffic and trace_ms[b] > 0) else None,
+                    "limiter": "not HBM: dependent-load latency at the occupancy the kernel reaches, then VALU issue (DESIGN.md section 6); "
+                               "`achieved` prices device-counted visits at SURVEY 8d's 64 B / 48 B, most of which the L2 / Infinity Cache serve",
                     "algorithmic_bytes_per_launch": algo_bytes, "launch_ms": trace_ms[b],
                     "launch_ms_overlapped_in_timed_region": [kernel_ms[0], kernel_ms[2], kernel_ms[4], kernel_ms[6]][b],
                     "node_steps_per_ray": [cc.innerVisits[i] / max(1, cc.raysPerBounce[i]) for i in range(4)],
                     "leaf_tests_per_ray": [cc.leafTests[i] / max(1, cc.raysPerBounce[i]) for i in range(4)],
-                    "bytes_per_node_step_survey": 64.0, "bytes_per_leaf_test": 48.0,
-                    "requested_bytes_per_launch": requested_bytes, "requested_bytes_per_node_step": node_bytes,
-                    "requested_gbs": requested_bytes / (trace_ms[b] * 1e-3) / 1e9 if trace_ms[b] > 0 else 0.0,
+                    "bytes_per_node_step_survey": 64.0, "bytes_per_leaf_test_survey": 48.0,
+                    "requested_bytes_per_launch": node_bytes * inner + leaf_bytes * leaf,
+                    "requested_bytes_per_node_step": node_bytes, "requested_bytes_per_leaf_test": leaf_bytes,
+                    "requested_gbs": (node_bytes * inner + leaf_bytes * leaf) / (trace_ms[b] * 1e-3) / 1e9 if trace_ms[b] > 0 else 0.0,
                     "work_items_per_lane_pass": [(cc.innerVisits[i] + cc.leafTests[i]) / (64.0 * cc.wavePasses[i]) if cc.wavePasses[i] else None
                                                  for i in range(4)],
                     "algorithmic_bytes_per_ray_all_trace": (64.0 * sum(cc.innerVisits) + 48.0 * sum(cc.leafTests)) / max(1, all_rays),
-                    "vector_l1_front_end": l1}
+                    "vector_l1_front_end": {"lane_loads_issued_per_launch": lane_loads, "l1_accesses_per_launch_pmc": tcp_accesses,
+                                            "issued_per_clock_per_cu": lane_loads / cu_clocks if cu_clocks > 0 else None,
+                                            "per_clock_per_cu_pmc": (tcp_accesses / cu_clocks) if (tcp_accesses and cu_clocks > 0) else None,
+                                            "ceiling_per_clock_per_cu": 0.87, "ceiling_source": "tools/tcp_rate (profiles/r01_tcp_rate.txt)",
+                                            "clock_hz": clock_hz, "cus": props.multi_processor_count}}
         # the reference's own visit counts (its tree, no distance culling, binary nodes) for
         # the same rays, and the bandwidth they would amount to in this kernel's time ("work-equivalent")
-        if args.traversal != "exact":
+        if args.traversal != "exact" and not args.no_extras:
             refc = HIPShader(scene, device=local_rank, rank=rank, world_size=world, traversal=_capi.TRAVERSE_EXACT, count_stats=True,
                              frames_in_flight=1)
-            refc.frame_counter = args.warmup
-            refc.Render(None, cam)
+            step(refc, args.warmup)
             rc = refc.counters()
             refc.close()
             ref_inner = [rc.innerVisits[i] / max(1, rc.raysPerBounce[i]) for i in range(4)]
@@ -258,31 +311,41 @@ def main():
             roofline["reference_semantics"] = {
                 "node_visits_per_ray": ref_inner, "leaf_tests_per_ray": ref_leaf,
                 "work_equivalent_gbs": (64.0 * ref_inner[b] + 48.0 * ref_leaf[b]) * rays_b / (trace_ms[b] * 1e-3) / 1e9 if trace_ms[b] > 0 else 0.0,
-                "note": "visit counts of RTX_TRAVERSE_EXACT (the reference's tree, 64-byte binary nodes) on the same rays; work_equivalent = those bytes over this launch's time"}
-        extra["serial_kernel_ms_per_frame"] = {"primary": serial_ms[0], "shade0": serial_ms[1], "trace1": serial_ms[2],
-                                               "shade1": serial_ms[3], "trace2": serial_ms[4], "shade2": serial_ms[5],
-                                               "trace3": serial_ms[6], "shade3": serial_ms[7]}
+                "note": "visit counts of RTX_TRAVERSE_EXACT (the reference's tree, 64-byte binary nodes) on the same rays; "
+                        "work_equivalent = those bytes over this launch's time. leaf_tests_per_ray equals the wide walk's: same leaf set"}
+        extra["serial_kernel_ms_per_frame"] = dict(zip(names8, serial_ms))
         extra["serial_device_ms_per_frame"] = cc.totalMs / max(1, cc.frames)
 
-    # ---- the same frames without distance culling (RTX_TRAVERSE_WIDE: the reference's leaf set by construction) ----
-    if rank == 0 and world == 1 and args.traversal == "culled":
-        wide = HIPShader(scene, device=local_rank, traversal=_capi.TRAVERSE_WIDE, frames_in_flight=args.frames_in_flight)
+    # ---- the same frames with distance culling (opt-in mode; not exact by construction) ---------------------------
+    culled = None
+    if rank == 0 and world == 1 and args.traversal == "wide" and not args.no_extras:
+        other = HIPShader(scene, device=local_rank, traversal=_capi.TRAVERSE_CULLED, frames_in_flight=args.frames_in_flight)
         for i in range(args.warmup):
-            wide.frame_counter = i
-            wide.Render(None, cam)
-        wide.counters(); wide.reset_counters()
+            step(other, i)
+        other.counters(); other.reset_counters()
         t1 = time.perf_counter()
         for i in range(args.steps):
-            if args.orbit:
-                orbit_camera(cam, 0.1 * i, 0.1 * i)
-                wide.frame_counter = 0
-            else:
-                wide.frame_counter = args.warmup + i
-            wide.Render(None, cam)
-        cw = wide.counters()
+            step(other, args.warmup + i)
+        other.download_into(frame)
+        cw = other.counters()
         dt = time.perf_counter() - t1
-        extra["without_distance_culling"] = {"traversal": "wide", "mrays_per_s": float(cw.rays) / dt / 1e6, "ms_per_step": dt / args.steps * 1e3}
-        wide.close()
+        culled = {"traversal": "culled", "mrays_per_s": float(cw.rays) / dt / 1e6, "ms_per_step": dt / args.steps * 1e3,
+                  "cull_slack": other.info().cullSlack,
+                  "note": "RTX_TRAVERSE_CULLED, opt-in: nearest-first walk of 128-byte float nodes with distance culling; same image here, not a proof"}
+        other.close()
+
+    # ---- the reference's calling pattern, default hardware queues, in a process of its own ----------------------
+    sync = None
+    if rank == 0 and world == 1 and not args.no_extras and not args.orbit:
+        env = dict(os.environ)
+        env.pop("GPU_MAX_HW_QUEUES", None)
+        try:
+            out = subprocess.run([sys.executable, os.path.abspath(__file__), "--sync-only", "--workload", args.workload,
+                                  "--traversal", args.traversal, "--steps", str(args.steps)], env=env, capture_output=True, text=True, timeout=240)
+            line = [l for l in out.stdout.splitlines() if l.startswith("{")]
+            sync = json.loads(line[-1]) if line else {"error": (out.stderr or out.stdout)[-400:]}
+        except Exception as e:
+            sync = {"error": str(e)}
 
     # ---- CPU baseline: the oracle (CPU restatement of ThreadedShader) on a bounded sample ----
     cpu = None
@@ -292,29 +355,39 @@ def main():
         fc = args.warmup
         px = np.zeros((H, W, 4), dtype=np.float32)
         mid = H // 2
-        t1 = time.perf_counter()
-        st = oracle.render(desc, cam, fc, px, nthreads=cores, rows=(mid - 4, mid + 4), stats=1)
-        probe = time.perf_counter() - t1
-        rows = int(max(8, min(H, 8 * args.cpu_seconds / max(probe, 1e-3))))
-        y0 = max(0, mid - rows // 2)
-        dt, cpu_rays, cpu_frames = 0.0, 0, 0
-        while cpu_frames == 0 or (rows == H and dt < args.cpu_seconds and cpu_frames < 8):
+
+        def time_oracle(L, seconds):
             t1 = time.perf_counter()
-            st = oracle.render(desc, cam, fc + cpu_frames, px, nthreads=cores, rows=(y0, y0 + rows), stats=1)
-            dt += time.perf_counter() - t1
-            cpu_rays += st.rays
-            cpu_frames += 1
-        cpu = {"value": cpu_rays / dt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
-               "sample": f"rows {y0}..{y0 + rows} of {H} ({rows * W} pixels) of frames {fc}..{fc + cpu_frames - 1} of the same scene, "
-                         f"{cpu_rays} rays, oracle/liboracle.so (strict -O2 restatement of ThreadedShader), {dt:.1f} s"}
+            oracle.render_bands(desc, cam, fc, px, nthreads=cores, rows=(mid - 8, mid + 8), L=L)
+            probe = time.perf_counter() - t1
+            rows = int(max(cores, min(H, 16 * seconds / max(probe, 1e-3))))
+            y0 = max(0, mid - rows // 2)
+            t1 = time.perf_counter()
+            st = oracle.render_bands(desc, cam, fc, px, nthreads=cores, rows=(y0, y0 + rows), L=L)
+            dt = time.perf_counter() - t1
+            return st.rays / dt / 1e6, f"rows {y0}..{y0 + rows} of {H} ({rows * W} pixels) of frame {fc} of the same scene, {st.rays} rays, {dt:.1f} s"
+        v, sample = time_oracle(None, args.cpu_seconds)
+        cpu = {"value": v, "unit": "Mrays/s", "cores": cores, "kind": "port",
+               "sample": sample + "; oracle/liboracle.so = strict -O2 restatement of ThreadedShader, static row bands as src/ThreadedShader.cpp:186-207"}
+        Lf = oracle.lib_ofast()
+        if Lf is not None:
+            vf, samplef = time_oracle(Lf, args.cpu_seconds / 2)
+            cpu["ofast"] = {"value": vf, "unit": "Mrays/s", "cores": cores,
+                            "sample": samplef + "; the same source with the reference's shipped flags (-Ofast, CMakeLists.txt:11)"}
 
     if rank == 0:
         out = {"metric": "Mrays/s", "value": rays / elapsed / 1e6, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
                "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": args.workload, "triangles": ntri, "resolution": [W, H], "bounces": 4,
-                          "spp_per_step": 1, "traversal": args.traversal, "partition": f"tiles64x32 round-robin x{world}",
-                          "camera": "orbit" if args.orbit else "fixed", "collective": backend if use_dist else None, "frames_in_flight": args.frames_in_flight or 14, "frames_per_batch": int(os.environ.get("RTX_BATCH", min(world, 8))), "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES")},
+                          "spp_per_step": 1, "traversal": args.traversal, "traversal_in_effect": {v: k for k, v in modes.items()}[info.traversal],
+                          "exact_by_construction": args.traversal != "culled",
+                          "partition": f"tiles64x32 round-robin x{world}",
+                          "camera": "orbit" if args.orbit else "fixed", "collective": backend if use_dist else None,
+                          "timed_region": "K x rtx_render(pixels=NULL) + tile gather to rank 0 + one device-to-host copy of the frame",
+                          "frames_in_flight": info.framesInFlight, "frames_per_batch": info.framesPerBatch,
+                          "GPU_MAX_HW_QUEUES": info.hwQueues},
+               "sync_boundary": sync, "culled_opt_in": culled,
                "roofline": roofline, "cpu_baseline": cpu, "extra": extra}
         print(json.dumps(out), flush=True)
     if use_dist:

@@ -58,6 +58,7 @@ struct RtxRenderer {
     DevScene sc{};
     // device allocations
     float4 *dFast = nullptr;
+    uint4* dQNodes = nullptr;
     int2* dSpill = nullptr;
     uint32_t* dSlow = nullptr;
     size_t ldsSlow = 0;
@@ -134,6 +135,7 @@ namespace {
 struct Flat {
     std::vector<float4> inner, leaf, shade;
     std::vector<rtxbuild::Node4> fast;  // own 4-wide SAH tree over the same leaves (empty: not built)
+    std::vector<rtxbuild::NodeQ> qnodes; // the same tree with byte boxes (RTX_TRAVERSE_WIDE); `fast` is dropped when this is built
     int rootRef = 0, fastRoot = 0;
     int maxDepth = 0, fastDepth = 0;
     bool nested = true;                 // every box contains its children (precondition of the own tree)
@@ -147,7 +149,7 @@ inline float i2f(int32_t v) { float f; memcpy(&f, &v, 4); return f; }
 // first and accepts a hit only when strictly closer (src/ThreadedShader.cpp:370,380-392), so among equal t the leaf it
 // visits first wins = the one with the LARGEST left-first rank. For trees numbered like BVHTree::Insert numbers them
 // (pre-order, left subtree first, src/BVHTree.cpp:160,180-183) the rank orders leaves exactly like their boxID.
-void emit_leaf(const RtxObject& o, int32_t objectID, int32_t boxID, int32_t tieRank, float4* leaf, float4* shade) {
+void emit_leaf(const RtxObject& o, int32_t objectID, int32_t boxID, int32_t tieRank, const RtxBoundingBox* box, float4* leaf, float4* shade) {
     const RtxVec4 A = o.vertices[0], B = o.vertices[1], C = o.vertices[2];
     float4 old[4];      // the shading record keeps (e2.z objectID boxID type) / (B.x B.y C.x C.y) in its third and fourth quad
     if (o.type == RTX_TRIANGLE) {
@@ -170,8 +172,10 @@ void emit_leaf(const RtxObject& o, int32_t objectID, int32_t boxID, int32_t tieR
     const int32_t tag = (int32_t)(((uint32_t)tieRank << 3) | (o.type == RTX_TRIANGLE ? 4u : 0u));
     leaf[0] = old[0];
     leaf[1] = old[1];
-    leaf[2] = make_float4(old[2].x, i2f(tag), 0.0f, 0.0f);
-    leaf[3] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    // ... followed by the leaf's own box as the caller gave it (the unordered walk tests it here, rtx_traverse.h q_leaf)
+    leaf[2] = make_float4(old[2].x, i2f(tag), box ? box->minimalPosition.x : 0.0f, box ? box->minimalPosition.y : 0.0f);
+    leaf[3] = box ? make_float4(box->minimalPosition.z, box->maximalPosition.x, box->maximalPosition.y, box->maximalPosition.z)
+                  : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     const RtxVec4 n0 = o.normals[0], n1 = o.normals[1], n2 = o.normals[2];
     // the shading record is one 128-byte line of its own: the primitive (hit_normal needs the
     // vertices) followed by the normals and the material, so that k_shade touches ONE scattered line per hit
@@ -218,7 +222,7 @@ struct ErrorSlot {
     bool any() { std::lock_guard<std::mutex> g(m); return !msg.empty(); }
 };
 
-int flatten(const RtxSceneDesc& s, bool useBVH, bool wantFast, int nthreads, Flat& f) {
+int flatten(const RtxSceneDesc& s, bool useBVH, bool wantFast, bool wantQuant, int nthreads, Flat& f) {
     PhaseClock clock;
     const uint64_t nObj = s.numObjects, nBox = s.numBoxes;
     ErrorSlot err;
@@ -254,7 +258,7 @@ int flatten(const RtxSceneDesc& s, bool useBVH, bool wantFast, int nthreads, Fla
     if (!useBVH) {
         f.leaf.resize(nObj * 4); f.shade.resize(nObj * 8);
         parallel_for(nObj, nthreads, [&](uint64_t b, uint64_t e) {
-            for (uint64_t i = b; i < e; ++i) emit_leaf(s.objects[i], (int32_t)i, (int32_t)i, 0, &f.leaf[i * 4], &f.shade[i * 8]);
+            for (uint64_t i = b; i < e; ++i) emit_leaf(s.objects[i], (int32_t)i, (int32_t)i, 0, nullptr, &f.leaf[i * 4], &f.shade[i * 8]);
         });
         f.rootRef = 0; f.maxDepth = 0;
         return 0;
@@ -413,6 +417,21 @@ int flatten(const RtxSceneDesc& s, bool useBVH, bool wantFast, int nthreads, Fla
         rtxbuild::single_leaf_node4(nLeaf == 1 ? &b : nullptr, f.fast);
         f.fastRoot = 0; f.fastDepth = 0;
     }
+    if (wantQuant && !f.fast.empty()) {
+        // RTX_TRAVERSE_WIDE: byte boxes, children regrouped (inner first, leaves as neighbours): a new leaf order
+        std::vector<uint32_t> newToOld;
+        if (rtxbuild::quantize4(f.fast, f.qnodes, newToOld, nthreads) && newToOld.size() == (size_t)nLeaf) {
+            std::vector<uint32_t> order2((size_t)nLeaf);
+            parallel_for((uint64_t)nLeaf, nthreads, [&](uint64_t p0, uint64_t p1) { for (uint64_t p = p0; p < p1; ++p) order2[p] = order[newToOld[p]]; });
+            order.swap(order2);
+            std::vector<rtxbuild::Node4>().swap(f.fast);
+        } else {
+            f.qnodes.clear();          // a box extent that is not finite: keep the reference topology
+            std::vector<rtxbuild::Node4>().swap(f.fast);
+            for (int32_t k = 0; k < nLeaf; ++k) order[k] = (uint32_t)k;
+        }
+        f.seconds[1] += clock.lap("quantise nodes");
+    }
     // leaves in the new order; reference leaf index -> position
     std::vector<int32_t> posOf((size_t)nLeaf);
     f.leaf.resize((size_t)nLeaf * 4); f.shade.resize((size_t)nLeaf * 8);
@@ -424,7 +443,7 @@ int flatten(const RtxSceneDesc& s, bool useBVH, bool wantFast, int nthreads, Fla
             const size_t k = order[p];
             const int32_t part = rankPart[k];
             const int32_t rank = (int32_t)std::max<int64_t>(0, partBase[(size_t)part] + (partCount[(size_t)part] - 1 - rankLocal[k]));
-            emit_leaf(s.objects[s.boxes[b].objectID], s.boxes[b].objectID, b, rank, &f.leaf[(size_t)p * 4], &f.shade[(size_t)p * 8]);
+            emit_leaf(s.objects[s.boxes[b].objectID], s.boxes[b].objectID, b, rank, &s.boxes[b], &f.leaf[(size_t)p * 4], &f.shade[(size_t)p * 8]);
         }
     });
     // the reference's own topology (used by RTX_TRAVERSE_EXACT and by lanes that cannot use the own tree)
@@ -556,15 +575,22 @@ void dispatch_primary(RtxRenderer* r, const DevBatch& bt, int workIdx) {
     if (r->mode == RTX_MODE_LINEAR) launch_primary<RTX_MODE_LINEAR>(r, bt, workIdx);
     else if (r->mode == RTX_MODE_EXACT) launch_primary<RTX_MODE_EXACT>(r, bt, workIdx);
     else if (r->mode == RTX_MODE_CULLED_BIG) launch_primary<RTX_MODE_CULLED_BIG>(r, bt, workIdx);
+    else if (r->mode == RTX_MODE_WIDEQ) launch_primary<RTX_MODE_WIDEQ>(r, bt, workIdx);
+    else if (r->mode == RTX_MODE_WIDEQ_BIG) launch_primary<RTX_MODE_WIDEQ_BIG>(r, bt, workIdx);
     else launch_primary<RTX_MODE_CULLED>(r, bt, workIdx);
 }
 // fixedCount: queue length when it is known on the host (bounce 0 / probes), else read from ctrl[countIdx]
 void dispatch_trace(RtxRenderer* r, const float4* o, const float4* d, int countIdx, int workIdx, uint32_t fixedCount) {
-    if (r->mode == RTX_MODE_CULLED || r->mode == RTX_MODE_CULLED_BIG) {
-        const bool big = r->mode == RTX_MODE_CULLED_BIG;
+    if (r->mode == RTX_MODE_CULLED || r->mode == RTX_MODE_CULLED_BIG || r->mode == RTX_MODE_WIDEQ || r->mode == RTX_MODE_WIDEQ_BIG) {
+        const bool big = r->mode == RTX_MODE_CULLED_BIG || r->mode == RTX_MODE_WIDEQ_BIG;
+        const bool quant = r->mode == RTX_MODE_WIDEQ || r->mode == RTX_MODE_WIDEQ_BIG;
         switch (countIdx * 4 + (r->cfg.countStats ? 2 : 0) + (big ? 1 : 0)) {
 #define RTX_REFILL_CASE(B, C, G)                                                                                              \
         case (B) * 4 + ((C) ? 2 : 0) + ((G) ? 1 : 0):                                                                          \
+            if (quant)                                                                                                         \
+            hipLaunchKernelGGL((k_trace_q<C, B, G>), dim3(r->launchTrace), dim3(RTX_BLOCK), r->ldsTrace, r->stream, r->sc,     \
+                               o, d, r->dHitT, r->dHitLeaf, r->dCtrl, r->dStats, r->dSlow, fixedCount, workIdx);               \
+            else                                                                                                               \
             hipLaunchKernelGGL((k_trace_refill<C, B, G>), dim3(r->launchTrace), dim3(RTX_BLOCK), r->ldsTrace, r->stream, r->sc, \
                                o, d, r->dHitT, r->dHitLeaf, r->dCtrl, r->dStats, r->dSlow, fixedCount, workIdx);               \
             break;
@@ -613,7 +639,7 @@ void rtx_destroy(RtxRenderer* r) {
     }
     if (r->hStage) hipHostFree(r->hStage);
     for (hipEvent_t e : r->stageEv) hipEventDestroy(e);
-    void* ptrs[] = {r->dFast, r->dInner, r->dLeaf, r->dShade, r->dMaterials, r->dTexInfo, r->dTexels, r->dTiles, r->dFb, r->dStats};
+    void* ptrs[] = {r->dFast, r->dQNodes, r->dInner, r->dLeaf, r->dShade, r->dMaterials, r->dTexInfo, r->dTexels, r->dTiles, r->dFb, r->dStats};
     for (void* p : ptrs) if (p) hipFree(p);
     for (int2* p : r->dTilesOfRank) if (p) hipFree(p);
     for (int i = 0; i < kRing; ++i) for (int k = 0; k < kEvents; ++k) if (r->ev[i][k]) hipEventDestroy(r->ev[i][k]);
@@ -654,8 +680,9 @@ int rtx_create(const RtxSceneDesc* scene, const RtxConfig* cfgIn, RtxRenderer** 
     if (cfg.traversal != RTX_TRAVERSE_CULLED && cfg.traversal != RTX_TRAVERSE_EXACT && cfg.traversal != RTX_TRAVERSE_WIDE)
         return fail("RtxConfig.traversal: unknown mode");
     const bool wantFast = cfg.traversal != RTX_TRAVERSE_EXACT;
+    const bool wantQuant = cfg.traversal == RTX_TRAVERSE_WIDE && !getenv("RTX_WIDE_ORDERED");
     PhaseClock createClock;
-    if (flatten(*scene, useBVH, wantFast, 16, flat)) return 1;
+    if (flatten(*scene, useBVH, wantFast, wantQuant, 16, flat)) return 1;
     createClock.lap("flatten");
     if (useBVH && flat.maxDepth > 62) return fail("BVH deeper than 62 levels is not supported (the reference's own stack holds 32)");
 
@@ -665,10 +692,13 @@ int rtx_create(const RtxSceneDesc* scene, const RtxConfig* cfgIn, RtxRenderer** 
     r->width = scene->width; r->height = scene->height;
     r->linear = !useBVH;
     // distance culling needs boxes that contain their descendants; otherwise keep the reference's visit set
-    r->mode = r->linear ? RTX_MODE_LINEAR : ((cfg.traversal == RTX_TRAVERSE_EXACT || !flat.nested || flat.fast.empty()) ? RTX_MODE_EXACT : RTX_MODE_CULLED);
-    const size_t bigNodes = (size_t)1 << 25;
+    r->mode = r->linear ? RTX_MODE_LINEAR : ((cfg.traversal == RTX_TRAVERSE_EXACT || !flat.nested || (flat.fast.empty() && flat.qnodes.empty())) ? RTX_MODE_EXACT
+                                             : (flat.qnodes.empty() ? RTX_MODE_CULLED : RTX_MODE_WIDEQ));
+    const size_t bigNodes = (size_t)1 << 25;      // 128-byte nodes / 64-byte nodes: 4 GiB of either
     if (r->mode == RTX_MODE_CULLED && (flat.fast.size() > bigNodes || getenv("RTX_FORCE_BIG"))) r->mode = RTX_MODE_CULLED_BIG;
-    const bool culled = r->mode == RTX_MODE_CULLED || r->mode == RTX_MODE_CULLED_BIG;
+    if (r->mode == RTX_MODE_WIDEQ && (flat.qnodes.size() > 2 * bigNodes || getenv("RTX_FORCE_BIG"))) r->mode = RTX_MODE_WIDEQ_BIG;
+    const bool quant = r->mode == RTX_MODE_WIDEQ || r->mode == RTX_MODE_WIDEQ_BIG;
+    const bool culled = r->mode == RTX_MODE_CULLED || r->mode == RTX_MODE_CULLED_BIG || quant;      // any walk of the own tree
     r->tileW = cfg.tileW; r->tileH = cfg.tileH;
 
 #define CREATE_TRY(expr) do { if (expr) { rtx_destroy(r); return 1; } } while (0)
@@ -716,6 +746,7 @@ int rtx_create(const RtxSceneDesc* scene, const RtxConfig* cfgIn, RtxRenderer** 
     // scene
     CREATE_TRY(upload(&r->dInner, flat.inner.data(), flat.inner.size() * sizeof(float4)));
     if (!flat.fast.empty()) CREATE_TRY(upload(&r->dFast, flat.fast.data(), flat.fast.size() * sizeof(rtxbuild::Node4)));
+    if (!flat.qnodes.empty()) CREATE_TRY(upload(&r->dQNodes, flat.qnodes.data(), flat.qnodes.size() * sizeof(rtxbuild::NodeQ)));
     CREATE_TRY(upload(&r->dLeaf, flat.leaf.data(), flat.leaf.size() * sizeof(float4)));
     CREATE_TRY(upload(&r->dShade, flat.shade.data(), flat.shade.size() * sizeof(float4)));
     CREATE_TRY(upload(&r->dMaterials, scene->materials, scene->numMaterials * sizeof(RtxMaterial)));
@@ -728,8 +759,9 @@ int rtx_create(const RtxSceneDesc* scene, const RtxConfig* cfgIn, RtxRenderer** 
     r->sc.rootRef = flat.rootRef;
     r->sc.fast = r->dFast;            // 4-wide nodes, 8 float4 each (NULL unless the mode is CULLED / CULLED_BIG)
     r->sc.fastRoot = flat.fastRoot;
+    r->sc.qnodes = r->dQNodes;
     r->sc.cullSlack = (flat.sliverFraction > 1e-3 || cfg.traversal == RTX_TRAVERSE_WIDE) ? INFINITY : RTX_CULL_SLACK_DEFAULT;
-    if (const char* e = getenv("RTX_CULL_SLACK")) r->sc.cullSlack = (float)atof(e);      // experiments ("inf" disables culling)
+    if (const char* e = getenv("RTX_CULL_SLACK")) if (cfg.traversal == RTX_TRAVERSE_CULLED) r->sc.cullSlack = (float)atof(e);      // experiments
     r->sc.numLeaves = (int)(flat.leaf.size() / 4);
     r->sc.numInner = (int)(flat.inner.size() / 4);
     r->sc.numMaterials = (int)scene->numMaterials;
@@ -739,7 +771,7 @@ int rtx_create(const RtxSceneDesc* scene, const RtxConfig* cfgIn, RtxRenderer** 
     r->sc.skyTex = scene->numTextures > 1 ? 1 : 0;
     r->sc.useBVH = useBVH ? 1 : 0;
     // reference topology: one pending entry per level; 4-wide tree: up to three per level
-    r->sc.stackDepth = std::max(2, std::max(flat.maxDepth, flat.fast.empty() ? 0 : 3 * (flat.fastDepth + 1)) + 2);
+    r->sc.stackDepth = std::max(2, std::max(flat.maxDepth, (flat.fast.empty() && flat.qnodes.empty()) ? 0 : 3 * (flat.fastDepth + 1)) + 2);
 
     // persistent shade grid: as many blocks as are resident at once
     int shadeBlocksPerCU = 0;
@@ -766,7 +798,7 @@ int rtx_create(const RtxSceneDesc* scene, const RtxConfig* cfgIn, RtxRenderer** 
 
     // launch geometry: persistent grids sized by the LDS the traversal stack needs
     // culled path: a fixed window of the stack in LDS; exact path: the whole stack (refs only)
-    r->ldsTrace = r->linear ? 0 : (culled ? (size_t)2 * RTX_LDS_WINDOW : (size_t)r->sc.stackDepth) * RTX_BLOCK * sizeof(int);
+    r->ldsTrace = r->linear ? 0 : (quant ? (size_t)RTX_QWORDS : culled ? (size_t)2 * RTX_LDS_WINDOW : (size_t)r->sc.stackDepth) * RTX_BLOCK * sizeof(int);
 
     int blocksPerCU = 8;
     if (r->ldsTrace) blocksPerCU = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / r->ldsTrace));
@@ -811,12 +843,12 @@ int rtx_create(const RtxSceneDesc* scene, const RtxConfig* cfgIn, RtxRenderer** 
         RtxInfo& in = r->info;
         in.traversal = r->linear ? RTX_TRAVERSE_EXACT : (culled ? (std::isinf(r->sc.cullSlack) ? RTX_TRAVERSE_WIDE : RTX_TRAVERSE_CULLED) : RTX_TRAVERSE_EXACT);
         in.linear = r->linear ? 1 : 0;
-        in.bigNodes = r->mode == RTX_MODE_CULLED_BIG ? 1 : 0;
+        in.bigNodes = (r->mode == RTX_MODE_CULLED_BIG || r->mode == RTX_MODE_WIDEQ_BIG) ? 1 : 0;
         in.cullSlack = culled ? r->sc.cullSlack : INFINITY;
         in.framesInFlight = depth; in.framesPerBatch = r->batch; in.hwQueues = hwQueues;
-        in.refTreeDepth = flat.maxDepth; in.wideTreeDepth = flat.fast.empty() ? 0 : flat.fastDepth;
+        in.refTreeDepth = flat.maxDepth; in.wideTreeDepth = (flat.fast.empty() && flat.qnodes.empty()) ? 0 : flat.fastDepth;
         in.stackEntries = r->sc.stackDepth;
-        in.leaves = (uint64_t)r->sc.numLeaves; in.innerNodes = (uint64_t)r->sc.numInner; in.wideNodes = flat.fast.size();
+        in.leaves = (uint64_t)r->sc.numLeaves; in.innerNodes = (uint64_t)r->sc.numInner; in.wideNodes = flat.fast.size() + flat.qnodes.size();
         in.sliverFraction = flat.sliverFraction;
         if (hipMemGetInfo(&freeAfter, &totalMem) == hipSuccess && freeBefore > freeAfter) r->deviceBytes = freeBefore - freeAfter;
         in.deviceBytes = r->deviceBytes;

@@ -434,4 +434,113 @@ inline void single_leaf_node4(const Box* leafBox, std::vector<Node4>& out) {
     }
 }
 
+// ---- quantised 4-wide nodes ----------------------------------------------------------
+// RTX_TRAVERSE_WIDE never culls by distance and never needs an order, so an inner test only has to be
+// CONSERVATIVE: it must pass whenever the exact test of a leaf below it passes (the leaf's own exact box,
+// stored with the leaf, has the last word). A node therefore stores its children's boxes as bytes on a grid
+// of 256 steps per axis spanned from the node's corner: plane = fma(byte, 2^e, origin), one rounding, and the
+// bytes are chosen so that the DECODED float plane lies outside the child's float box (lo rounded down, hi up,
+// verified with the same fma). The kernel then applies the reference's own (p - o) * inv to the decoded
+// plane; that function is monotonic in p under IEEE rounding, hence decoded box contains child box =>
+// entry <= child's entry, exit >= child's exit: whenever a descendant leaf passes, every node above it passes.
+// 48 bytes instead of 112: three 16-byte lane loads per step instead of seven (the traversal kernels are
+// bound by the number of lane loads the vector L1 accepts).
+//
+// Children are sorted inner first, then leaves; a node's inner children are neighbours in the node array and
+// its leaf children are neighbours in the leaf array, so the node stores two bases instead of four refs:
+// child in slot j = node baseInner + j, or leaf baseLeaf + j (bases are pre-biased; slots are what the valid /
+// leaf masks and the byte lanes are indexed by).
+struct NodeQ {          // 64-byte slot, 48 bytes used
+    // w[0..2] origin.xyz  w[3] = ex | ey << 8 | ez << 16 | valid << 24 | leaf << 28   (e* = biased float exponent of the step)
+    // w[4] lo.x bytes (slot j in byte j)  w[5] hi.x  w[6] lo.y  w[7] hi.y  w[8] lo.z  w[9] hi.z  w[10] baseInner  w[11] baseLeaf
+    uint32_t w[16];
+};
+
+// Converts the Node4 tree (root = node 0) into NodeQ records (root = node 0 again) and returns, for every new leaf
+// position, the position the leaf had in the order the Node4 tree refers to. false: a box extent is not finite
+// (the caller keeps the reference topology then).
+inline bool quantize4(const std::vector<Node4>& in, std::vector<NodeQ>& out, std::vector<uint32_t>& leafNewToOld, int nthreads) {
+    const int32_t kNone = (int32_t)0x80000000;
+    const size_t n = in.size();
+    struct Plan { int32_t newIdx, baseInner, baseLeaf; uint8_t slot[4], ni, nl; };
+    std::vector<Plan> plan(n);
+    leafNewToOld.clear();
+    // numbering: a node's inner children take consecutive indices, handed out when the node is visited; the walk
+    // then descends into the first child, so a subtree's blocks stay near each other in memory
+    {
+        std::vector<int32_t> st; st.push_back(0);
+        plan[0].newIdx = 0;
+        int32_t nextNode = 1;
+        while (!st.empty()) {
+            const int32_t i = st.back(); st.pop_back();
+            Plan& p = plan[(size_t)i];
+            const float* q = in[(size_t)i].q;
+            p.ni = p.nl = 0;
+            for (int k = 0; k < 4; ++k) { const int32_t r = f2i(q[24 + k]); if (r >= 0) p.slot[p.ni++] = (uint8_t)k; }
+            for (int k = 0; k < 4; ++k) { const int32_t r = f2i(q[24 + k]); if (r < 0 && r != kNone) p.slot[p.ni + p.nl++] = (uint8_t)k; }
+            p.baseInner = nextNode;
+            p.baseLeaf = (int32_t)leafNewToOld.size() - (int32_t)p.ni;
+            for (int j = 0; j < p.ni; ++j) plan[(size_t)f2i(q[24 + p.slot[j]])].newIdx = nextNode++;
+            for (int j = 0; j < p.nl; ++j) leafNewToOld.push_back((uint32_t)~f2i(q[24 + p.slot[p.ni + j]]));
+            for (int j = p.ni; j-- > 0;) st.push_back(f2i(q[24 + p.slot[j]]));
+        }
+    }
+    out.assign(n, NodeQ{});
+    std::vector<uint8_t> bad((size_t)std::max(1, nthreads), 0);
+    auto work = [&](int t, size_t b, size_t e) {
+        for (size_t i = b; i < e; ++i) {
+            const Plan& p = plan[i];
+            const float* q = in[i].q;
+            NodeQ& o = out[(size_t)p.newIdx];
+            const int nc = p.ni + p.nl;
+            uint32_t meta = 0;
+            for (int a = 0; a < 3; ++a) {
+                float lo = INFINITY, hi = -INFINITY;
+                for (int j = 0; j < nc; ++j) { lo = std::min(lo, q[8 * a + p.slot[j]]); hi = std::max(hi, q[8 * a + 4 + p.slot[j]]); }
+                if (nc == 0) { lo = 0.0f; hi = 0.0f; }
+                const double ext = (double)hi - (double)lo;
+                if (!std::isfinite(ext) || !std::isfinite(lo) || ext < 0.0) { bad[(size_t)t] = 1; lo = 0.0f; hi = 0.0f; }
+                int eb = 1;                                           // biased exponent of the grid step, 1..254
+                if (ext > 0.0 && std::isfinite(ext)) { int ex; std::frexp(ext / 255.0, &ex); eb = std::min(254, std::max(1, ex + 127)); }   // 2^ex >= ext / 255
+                uint32_t wl = 0, wh = 0;
+                for (;;) {
+                    const float step = i2f(eb << 23);
+                    bool fits = true; wl = 0; wh = 0;
+                    for (int j = 0; j < nc && fits; ++j) {
+                        const float clo = q[8 * a + p.slot[j]], chi = q[8 * a + 4 + p.slot[j]];
+                        int ql = (int)std::floor(((double)clo - (double)lo) / (double)step);
+                        ql = std::min(255, std::max(0, ql));
+                        while (ql > 0 && std::fmaf((float)ql, step, lo) > clo) --ql;            // decoded plane must not lie inside
+                        int qh = (int)std::ceil(((double)chi - (double)lo) / (double)step);
+                        qh = std::max(0, qh);
+                        while (qh <= 255 && std::fmaf((float)qh, step, lo) < chi) ++qh;
+                        if (qh > 255) { fits = false; break; }
+                        wl |= (uint32_t)ql << (8 * j); wh |= (uint32_t)qh << (8 * j);
+                    }
+                    if (fits) break;
+                    if (eb >= 254) { bad[(size_t)t] = 1; break; }
+                    ++eb;
+                }
+                o.w[a] = (uint32_t)f2i(lo);
+                meta |= (uint32_t)eb << (8 * a);
+                o.w[4 + 2 * a] = wl; o.w[5 + 2 * a] = wh;
+            }
+            meta |= ((1u << nc) - 1u) << 24;
+            meta |= (((1u << nc) - 1u) & ~((1u << p.ni) - 1u)) << 28;
+            o.w[3] = meta;
+            o.w[10] = (uint32_t)p.baseInner; o.w[11] = (uint32_t)p.baseLeaf;
+        }
+    };
+    if (nthreads > 1 && n > 4096) {
+        std::vector<std::thread> pool;
+        const size_t per = (n + (size_t)nthreads - 1) / (size_t)nthreads;
+        for (int t = 0; t < nthreads; ++t) { const size_t b = std::min(n, (size_t)t * per), e = std::min(n, b + per); if (b < e) pool.emplace_back(work, t, b, e); }
+        for (auto& th : pool) th.join();
+    } else {
+        work(0, 0, n);
+    }
+    for (uint8_t b : bad) if (b) return false;
+    return true;
+}
+
 } // namespace rtxbuild

@@ -6,8 +6,10 @@
 //             q2 = (lo1.z hi1.x hi1.y hi1.z) q3 = (ref0 ref1 - -)      ref>=0 inner, ref<0 leaf ~ref
 //   fast[]   128 B / 4-wide node: the renderer's own SAH tree over the same leaves (rtx_build.h Node4):
 //             lo.x[4] hi.x[4] lo.y[4] hi.y[4] lo.z[4] hi.z[4] ref[4] pad[4]; an empty slot holds a NaN box
-//   leaf[]    64 B / primitive  : q0 = (A.x A.y A.z e1.x) q1 = (e1.y e1.z e2.x e2.y) q2 = (e2.z boxID<<3|type - -)
-//             sphere: A = centre, e1.x = radius. A leaf test reads the first 40 bytes (three lane loads).
+//   qnodes[]  64 B / 4-wide node: the same tree with byte boxes (rtx_build.h NodeQ, 48 bytes used): RTX_TRAVERSE_WIDE
+//   leaf[]    64 B / primitive  : q0 = (A.x A.y A.z e1.x) q1 = (e1.y e1.z e2.x e2.y) q2 = (e2.z rank<<3|type lo.x lo.y)
+//             q3 = (lo.z hi.x hi.y hi.z): the primitive, its tie-break rank and its own exact box.
+//             sphere: A = centre, e1.x = radius. The ordered walks read the first 40 bytes (three lane loads).
 //   shade[]  128 B / primitive  : q0 q1 as in leaf[], q2 = (e2.z objectID boxID type) q3 = (B.x B.y C.x C.y),
 //                                 q4 = (n0.x n0.y n0.z n1.x) q5 = (n1.y n1.z n2.x n2.y)
 //                                 q6 = (n2.z materialID - -) q7 unused: one line per shaded hit
@@ -62,6 +64,7 @@ __device__ __forceinline__ float rtx_rand(uint32_t& seed) {
 struct DevScene {
     const float4* fast;   // own 4-wide SAH tree over the same leaves (may be NULL): 8 float4 per node (rtx_build.h Node4)
     int fastRoot;
+    const uint4* qnodes;  // quantised 4-wide nodes of RTX_TRAVERSE_WIDE (rtx_build.h NodeQ, 4 uint4 per node; root = node 0), or NULL
     const float4* inner;
     const float4* leaf;
     const float4* shade;

@@ -24,6 +24,8 @@
 #define RTX_MODE_EXACT 1
 #define RTX_MODE_LINEAR 2
 #define RTX_MODE_CULLED_BIG 3     // CULLED over a tree of more than 2^25 wide nodes (64-bit node addresses)
+#define RTX_MODE_WIDEQ 4          // RTX_TRAVERSE_WIDE: quantised nodes, unordered walk, no distance culling (rtx_traverse.h)
+#define RTX_MODE_WIDEQ_BIG 5      // ... over more than 2^26 nodes (64-bit node addresses)
 #define RTX_INVALID_SLOT (-2)
 
 // ctrl[] layout (uint32): [0..7] queue counts per bounce, [24..27] slow-list lengths, then the work counters:
@@ -127,13 +129,19 @@ __device__ __forceinline__ Hit closest_hit(const DevScene& sc, float ox, float o
                                            int* stack, uint32_t& ic, uint32_t& lc) {
     if (MODE == RTX_MODE_LINEAR) return traverse_linear<COUNT>(sc, ox, oy, oz, dx, dy, dz, lc);
     if (MODE == RTX_MODE_EXACT) return traverse_bvh<true, COUNT>(sc, ox, oy, oz, dx, dy, dz, stack, RTX_BLOCK, ic, lc);
-    // CULLED: clean lanes take the fast path; a lane whose slab test could produce NaN (axis-parallel
+    // own tree: clean lanes take the fast path; a lane whose slab test could produce NaN (axis-parallel
     // direction, non-finite input) walks the reference topology with the reference's exact semantics
     Hit h; h.t = INFINITY; h.leaf = -1; h.box = -1;
     const bool clean = lane_is_clean(ox, oy, oz, dx, dy, dz);
     const long long nthreads = (long long)gridDim.x * RTX_BLOCK;
     const long long gtid = (long long)blockIdx.x * RTX_BLOCK + threadIdx.x;
-    if (clean) {
+    if (MODE == RTX_MODE_WIDEQ || MODE == RTX_MODE_WIDEQ_BIG) {
+        if (clean) {
+            QStack st;
+            st.lds = (int)threadIdx.x; st.stride = RTX_BLOCK; st.spill = (int*)sc.spill + gtid; st.spillStride = nthreads; st.nsp = 0; st.nbase = 0; st.lsp = 0;
+            h = traverse_q<COUNT, MODE == RTX_MODE_WIDEQ_BIG>(sc, ox, oy, oz, dx, dy, dz, st, ic, lc);
+        }
+    } else if (clean) {
         LaneStack st;
         st.lds = (int)threadIdx.x; st.stride = RTX_BLOCK; st.spill = sc.spill + gtid; st.spillStride = nthreads; st.sp = 0; st.base = 0;
         h = traverse_fast<COUNT, MODE == RTX_MODE_CULLED_BIG>(sc, ox, oy, oz, dx, dy, dz, st, ic, lc);
@@ -374,6 +382,97 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_trace_refill(DevScene sc, const f
                 }
             }
             nIdle = __popcll(__ballot(cur == RTX_IDLE));
+        } while (drained ? nIdle < 64 : nIdle < RTX_REFILL_MIN);
+    }
+    if (COUNT) {
+        ic = wave_sum(ic); lc = wave_sum(lc);
+        if (lane == 0) {
+            atomicAdd(&stats[RTX_STAT_INNER(countIdx)], (unsigned long long)ic); atomicAdd(&stats[RTX_STAT_LEAF(countIdx)], (unsigned long long)lc);
+            atomicAdd(&stats[RTX_STAT_PASSES(countIdx)], (unsigned long long)wp);
+        }
+    }
+}
+
+// RTX_TRAVERSE_WIDE's bounce launch: the lane-refill loop of k_trace_refill around the unordered two-list pass of
+// rtx_traverse.h (q_pass). Same queue protocol, same outputs.
+template <bool COUNT, int BOUNCE, bool BIG>
+__global__ __launch_bounds__(RTX_BLOCK) void k_trace_q(DevScene sc, const float4* __restrict__ rqO, const float4* __restrict__ rqD,
+                                                       float* __restrict__ hitT, int* __restrict__ hitLeaf,
+                                                       uint32_t* __restrict__ ctrl, unsigned long long* __restrict__ stats,
+                                                       uint32_t* __restrict__ slowList, uint32_t fixedCount, int workIdx) {
+    const int countIdx = BOUNCE;
+    const uint32_t lane = threadIdx.x & 63u;
+    const unsigned long long laneLt = (1ull << lane) - 1ull;
+    const long long nthreads = (long long)gridDim.x * RTX_BLOCK;
+    const long long gtid = (long long)blockIdx.x * RTX_BLOCK + threadIdx.x;
+    QStack st;
+    st.lds = (int)threadIdx.x; st.stride = RTX_BLOCK; st.spill = (int*)sc.spill + gtid; st.spillStride = nthreads; st.nsp = 0; st.nbase = 0; st.lsp = 0;
+    const uint4* __restrict__ nodes = sc.qnodes;
+    const float4* __restrict__ leaves = sc.leaf;
+    const uint32_t count = countIdx == 0 ? fixedCount : ctrl[RTX_CTRL_COUNT(countIdx)];
+    if ((unsigned long long)blockIdx.x * (RTX_BLOCK * RTX_RAYS_PER_LANE) >= (unsigned long long)count && blockIdx.x > 0) return;
+    uint32_t ic = 0, lc = 0, wp = 0;
+    uint32_t rcur = 0, rend = 0;          // wave-uniform: the wave's reserved run of the queue
+    const uint32_t segLen = segment_length(count);
+    uint32_t seg = blockIdx.x & 7u, segsTried = 0;
+    bool drained = false;                 // wave-uniform
+    // per-lane ray state
+    bool busy = false;
+    uint32_t q = 0;
+    float dx = 0, dy = 0, dz = 0;
+    QRay r = q_ray(0, 0, 0, 1, 1, 1);
+    int nodeCur = 0, leafCur = 0;
+    Hit best; best.t = INFINITY; best.leaf = -1; best.box = -1;
+    for (;;) {
+        const unsigned long long idle = __ballot(!busy);
+        int nIdle = __popcll(idle);
+        if (!drained && nIdle >= RTX_REFILL_MIN) {
+            while (rcur >= rend && !drained) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(&ctrl[RTX_CTRL_XWORK(workIdx, seg)], RTX_RESERVE);
+                const uint32_t segStart = seg * segLen, segEnd = segStart + segLen < count ? segStart + segLen : count;
+                rcur = segStart + __builtin_amdgcn_readfirstlane(base);
+                rend = rcur + RTX_RESERVE < segEnd ? rcur + RTX_RESERVE : segEnd;
+                if (rcur >= segEnd || segStart >= count) {
+                    rend = rcur;
+                    seg = (seg + 1u) & 7u;
+                    if (++segsTried == 8u) drained = true;
+                }
+            }
+            if (!drained) {
+                const uint32_t avail = rend - rcur;
+                const uint32_t take = (uint32_t)nIdle < avail ? (uint32_t)nIdle : avail;
+                const uint32_t rank = (uint32_t)__popcll(idle & laneLt);
+                if (!busy && rank < take) {
+                    q = rcur + rank;
+                    const float4 o = rqO[q], d = rqD[q];
+                    dx = d.x; dy = d.y; dz = d.z;
+                    if (d.w != 0.0f) {
+                        hitLeaf[q] = RTX_INVALID_SLOT;     // slot outside the image, or a hole in a bounce queue
+                    } else if (lane_is_clean(o.x, o.y, o.z, dx, dy, dz)) {
+                        r = q_ray(o.x, o.y, o.z, 1.0f / dx, 1.0f / dy, 1.0f / dz);
+                        best.t = INFINITY; best.leaf = -1; best.box = -1;
+                        st.nsp = 0; st.nbase = 0; st.lsp = 0;
+                        nodeCur = RTX_QENTRY(0, 1); leafCur = 0;
+                        busy = true;
+                    } else {
+                        slowList[atomicAdd(&ctrl[RTX_CTRL_SLOW(countIdx)], 1u)] = q;
+                    }
+                }
+                rcur += take;
+            }
+            continue;
+        }
+        if (nIdle == 64) break;          // drained and nothing in flight
+        do {
+            if (COUNT) wp++;
+            if (busy) {
+                if (!q_pass<COUNT, BIG>(nodes, leaves, r, dx, dy, dz, nodeCur, leafCur, st, best, ic, lc)) {
+                    hitT[q] = best.t; hitLeaf[q] = best.leaf;
+                    busy = false;
+                }
+            }
+            nIdle = __popcll(__ballot(!busy));
         } while (drained ? nIdle < 64 : nIdle < RTX_REFILL_MIN);
     }
     if (COUNT) {

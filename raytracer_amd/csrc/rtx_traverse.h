@@ -379,6 +379,168 @@ __device__ __forceinline__ Hit traverse_fast(const DevScene& sc, float ox, float
     return best;
 }
 
+// ---- RTX_TRAVERSE_WIDE: quantised nodes, no order, no culling ---------------------------------------------------------
+// Without distance culling the set of leaves a ray tests does not depend on the order of the walk (a
+// leaf is tested iff its own box passes), so this path drops everything that only served the order: no sorting
+// network, no entry distances on the stack. And since the leaf's own exact box has the last word, the inner tests only
+// have to be conservative: 48-byte nodes with byte boxes (rtx_build.h NodeQ), three lane loads per step instead of seven.
+//
+// A lane keeps two work lists, inner nodes and leaves, each as a current entry plus a small LDS stack; an entry is
+// (base << 4 | 4-bit slot mask): "children base + j of one node, for every set bit j" — a node's passing inner children
+// are ONE entry, its passing leaf children another. Every pass a lane takes one node step and one leaf test, whichever
+// of the two it has, so the two sections of a pass run on well-filled waves and a ray needs about max(node steps,
+// leaf tests) passes instead of their interleaved sum.
+struct QRay { float ox, oy, oz, ix, iy, iz; bool nx, ny, nz; };   // n*: the reciprocal is negative, the near plane is hi
+__device__ __forceinline__ QRay q_ray(float ox, float oy, float oz, float ix, float iy, float iz) {
+    QRay r; r.ox = ox; r.oy = oy; r.oz = oz; r.ix = ix; r.iy = iy; r.iz = iz;
+    r.nx = ix < 0.0f; r.ny = iy < 0.0f; r.nz = iz < 0.0f;
+    return r;
+}
+
+#define RTX_QN 16          // node entries per lane kept in LDS (older ones spill to HBM; the stack is at most tree depth + 1 deep)
+#define RTX_QL 4           // leaf entries per lane; a lane whose leaf stack is full takes no node step until it has room
+#define RTX_QWORDS (RTX_QN + RTX_QL)
+
+struct QStack {
+    int lds, stride;           // this lane's LDS column: node entry k at rtx_lds[lds + (k % RTX_QN) * stride], leaf entry k at rtx_lds[lds + (RTX_QN + k) * stride]
+    int* spill;                // this thread's HBM column: node entry k at spill[k * spillStride]
+    long long spillStride;
+    int nsp, nbase, lsp;       // node entries [nbase, nsp) are in LDS, [0, nbase) in HBM; lsp leaf entries
+    __device__ __forceinline__ void push_node(int e) {
+        const int slot = nsp & (RTX_QN - 1);
+        if (nsp - nbase == RTX_QN) { spill[(long long)nbase * spillStride] = rtx_lds[lds + slot * stride]; nbase++; }
+        rtx_lds[lds + slot * stride] = e;
+        nsp++;
+    }
+    __device__ __forceinline__ int pop_node() {
+        nsp--;
+        if (nsp >= nbase) return rtx_lds[lds + (nsp & (RTX_QN - 1)) * stride];
+        nbase = nsp;
+        return spill[(long long)nsp * spillStride];
+    }
+    __device__ __forceinline__ void push_leaf(int e) { rtx_lds[lds + (RTX_QN + lsp) * stride] = e; lsp++; }
+    __device__ __forceinline__ int pop_leaf() { lsp--; return rtx_lds[lds + (RTX_QN + lsp) * stride]; }
+};
+
+#define RTX_QENTRY(base, mask) ((int)(((uint32_t)(base) << 4) | (mask)))
+
+// The three lane loads of a node step. BIG: node arrays beyond 4 GiB (2^26 nodes) take 64-bit lane addresses.
+struct QNodeData { uint4 a, b, c; };
+template <bool BIG>
+__device__ __forceinline__ QNodeData q_load_node(const uint4* __restrict__ nodes, int idx) {
+    QNodeData n;
+    if (BIG) {
+        const uint4* N = nodes + (size_t)(uint32_t)idx * 4;
+        n.a = N[0]; n.b = N[1]; n.c = N[2];
+    } else {
+        const char* base = (const char*)nodes;
+        const uint32_t off = (uint32_t)idx << 6;
+        n.a = *(const uint4*)(base + off); n.b = *(const uint4*)(base + off + 16); n.c = *(const uint4*)(base + off + 32);
+    }
+    return n;
+}
+
+// One step through a quantised node: returns the slots whose decoded box passes the reference's slab test.
+__device__ __forceinline__ uint32_t q_step(const QNodeData& n, const QRay& r, int& baseInner, int& baseLeaf, uint32_t& leafBits) {
+    const uint4 a = n.a, b = n.b, c = n.c;
+    const float orx = __uint_as_float(a.x), ory = __uint_as_float(a.y), orz = __uint_as_float(a.z);
+    const uint32_t meta = a.w;
+    const float sx = __uint_as_float((meta & 0xffu) << 23), sy = __uint_as_float((meta & 0xff00u) << 15), sz = __uint_as_float((meta & 0xff0000u) << 7);
+    const uint32_t nxw = r.nx ? b.y : b.x, fxw = r.nx ? b.x : b.y;
+    const uint32_t nyw = r.ny ? b.w : b.z, fyw = r.ny ? b.z : b.w;
+    const uint32_t nzw = r.nz ? c.y : c.x, fzw = r.nz ? c.x : c.y;
+    baseInner = (int)c.z; baseLeaf = (int)c.w; leafBits = meta >> 28;
+    uint32_t mask = 0;
+    // decoded plane = fma(byte, step, origin) (the value rtx_build.h verified against the child's box), then the
+    // reference's own (p - o) * inv: separate subtraction and multiplication. (Written for pairs of children as packed
+    // FP32 — v_pk_fma / v_pk_add / v_pk_mul — the step needs 108 registers instead of 77, occupancy falls from 6 to 4
+    // waves per SIMD and the bounce-1 launch goes from 3.15 to 3.36 ms; capped at 80 registers it spills: 5.2 ms.)
+#define RTX_QPLANE(word, k, st, org, o, i) ((fmaf((float)(((word) >> (8 * (k))) & 0xffu), st, org) - (o)) * (i))
+#define RTX_QCHILD(k) {                                                                                                      \
+        const float tn = fmaxf(RTX_QPLANE(nxw, k, sx, orx, r.ox, r.ix), fmaxf(RTX_QPLANE(nyw, k, sy, ory, r.oy, r.iy), RTX_QPLANE(nzw, k, sz, orz, r.oz, r.iz))); \
+        const float tf = fminf(RTX_QPLANE(fxw, k, sx, orx, r.ox, r.ix), fminf(RTX_QPLANE(fyw, k, sy, ory, r.oy, r.iy), RTX_QPLANE(fzw, k, sz, orz, r.oz, r.iz))); \
+        mask |= (tn <= tf && tf > 0.0f) ? (1u << (k)) : 0u; }
+    RTX_QCHILD(0) RTX_QCHILD(1) RTX_QCHILD(2) RTX_QCHILD(3)
+#undef RTX_QCHILD
+#undef RTX_QPLANE
+    return mask & ((meta >> 24) & 15u);
+}
+
+// Leaf record (64 bytes, four lane loads): q0 = (A.xyz e1.x) q1 = (e1.yz e2.xy) q2 = (e2.z tag lo.x lo.y) q3 = (lo.z hi.xyz)
+// — the primitive and its own EXACT box. The box is tested with the reference's arithmetic (planes picked by the sign of
+// the reciprocal, equal to the reference's min/max for a clean lane and min <= max); only if it passes is the primitive
+// intersected, which is exactly when the reference intersects it.
+struct QLeafData { float4 q0, q1, q2, q3; };
+__device__ __forceinline__ QLeafData q_load_leaf(const float4* __restrict__ leafBase, int leafIdx) {
+    const float4* L = leafBase + (size_t)leafIdx * 4;
+    QLeafData d; d.q0 = L[0]; d.q1 = L[1]; d.q2 = L[2]; d.q3 = L[3];
+    return d;
+}
+template <bool COUNT>
+__device__ __forceinline__ void q_leaf(const QLeafData& d, int leafIdx, const QRay& r, float dx, float dy, float dz,
+                                       Hit& best, uint32_t& leafCount) {
+    const float4 q0 = d.q0, q1 = d.q1, q2 = d.q2, q3 = d.q3;
+    const float lx = q2.z, ly = q2.w, lz = q3.x, hx = q3.y, hy = q3.z, hz = q3.w;
+    const float tn = fmaxf(((r.nx ? hx : lx) - r.ox) * r.ix, fmaxf(((r.ny ? hy : ly) - r.oy) * r.iy, ((r.nz ? hz : lz) - r.oz) * r.iz));
+    const float tf = fminf(((r.nx ? lx : hx) - r.ox) * r.ix, fminf(((r.ny ? ly : hy) - r.oy) * r.iy, ((r.nz ? lz : hz) - r.oz) * r.iz));
+    if (tn <= tf && tf > 0.0f) {
+        const int tag = __float_as_int(q2.y);
+        const int box = tag >> 3;
+        float t;
+        if ((tag & 7) == 4) t = intersect_triangle(r.ox, r.oy, r.oz, dx, dy, dz, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x);
+        else t = intersect_sphere(r.ox, r.oy, r.oz, dx, dy, dz, q0.x, q0.y, q0.z, q0.w);
+        if (COUNT) leafCount++;
+        if (t > 0.01f && (t < best.t || (t == best.t && best.leaf >= 0 && box > best.box))) { best.t = t; best.leaf = leafIdx; best.box = box; }
+    }
+}
+
+// One pass of a lane: a node step if it has a node (and room for the leaves the step may find) and a leaf test if it has
+// a leaf — the loads of both are issued together at the top of the pass, so a pass costs ONE memory round trip — then both
+// lists are topped up from their stacks. Returns false when the ray has nothing left to do.
+// (Running the leaf section only when enough lanes hold a leaf — leaves can wait, nothing depends on their order — was
+// tried with thresholds of 20 / 28 / 36 lanes and a starvation guard: every variant slower, 3.24 -> 3.5-3.9 ms on the
+// bounce-1 launch, because a lane that has run out of nodes idles until the section runs.)
+template <bool COUNT, bool BIG>
+__device__ __forceinline__ bool q_pass(const uint4* __restrict__ nodes, const float4* __restrict__ leaves, const QRay& r, float dx, float dy, float dz,
+                                       int& nodeCur, int& leafCur, QStack& st, Hit& best, uint32_t& innerCount, uint32_t& leafCount) {
+    const bool doNode = (nodeCur & 15) && st.lsp < RTX_QL;
+    const bool doLeaf = (leafCur & 15) != 0;
+    // Both records are loaded by every lane in the pass, a lane without a node (or leaf) reading record 0: the loads then
+    // sit in straight-line code ahead of everything that waits for them (inside divergent blocks the compiler parks
+    // copies behind each block, and the pass waits for memory twice); the idle lanes' reads of one address merge into
+    // one L1 access.
+    const int nodeIdx = doNode ? (nodeCur >> 4) + (__ffs(nodeCur & 15) - 1) : 0;
+    const QNodeData nd = q_load_node<BIG>(nodes, nodeIdx);
+    if (doNode) nodeCur &= nodeCur - 1;                 // clears the lowest set bit, which lies inside the slot mask
+    const int leafIdx = doLeaf ? (leafCur >> 4) + (__ffs(leafCur & 15) - 1) : 0;
+    const QLeafData ld = q_load_leaf(leaves, leafIdx);
+    if (doLeaf) leafCur &= leafCur - 1;
+    if (doNode) {
+        int bi, bl; uint32_t leafBits;
+        const uint32_t m = q_step(nd, r, bi, bl, leafBits);
+        if (COUNT) innerCount++;
+        const uint32_t mi = m & ~leafBits, ml = m & leafBits;
+        if (mi) { if (nodeCur & 15) st.push_node(nodeCur); nodeCur = RTX_QENTRY(bi, mi); }
+        if (ml) { if (leafCur & 15) st.push_leaf(leafCur); leafCur = RTX_QENTRY(bl, ml); }
+    }
+    if (doLeaf) q_leaf<COUNT>(ld, leafIdx, r, dx, dy, dz, best, leafCount);
+    if (!(nodeCur & 15) && st.nsp > 0) nodeCur = st.pop_node();
+    if (!(leafCur & 15) && st.lsp > 0) leafCur = st.pop_leaf();
+    return ((nodeCur | leafCur) & 15) != 0;
+}
+
+// closest hit of one ray per lane (primary rays: a wave's 64 rays are neighbours and run about equally long)
+template <bool COUNT, bool BIG>
+__device__ __forceinline__ Hit traverse_q(const DevScene& sc, float ox, float oy, float oz, float dx, float dy, float dz,
+                                          QStack st, uint32_t& innerCount, uint32_t& leafCount) {
+    Hit best; best.t = INFINITY; best.leaf = -1; best.box = -1;
+    const QRay r = q_ray(ox, oy, oz, 1.0f / dx, 1.0f / dy, 1.0f / dz);
+    st.nsp = 0; st.nbase = 0; st.lsp = 0;
+    int nodeCur = RTX_QENTRY(0, 1), leafCur = 0;         // the root is node 0
+    while (q_pass<COUNT, BIG>(sc.qnodes, sc.leaf, r, dx, dy, dz, nodeCur, leafCur, st, best, innerCount, leafCount)) {}
+    return best;
+}
+
 // Linear list (src/ThreadedShader.cpp:219-237): leaves are stored in object order.
 template <bool COUNT>
 __device__ __forceinline__ Hit traverse_linear(const DevScene& sc, float ox, float oy, float oz, float dx, float dy, float dz,

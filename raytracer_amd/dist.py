@@ -83,17 +83,26 @@ class DeviceGather:
         self.shader, self.rank, self.world, self.group = shader, rank, world_size, group
         self.host_staging = host_staging
         n = max(shader.packed_floats(r) for r in range(world_size))
-        self.send = torch.zeros(n, dtype=torch.float32, device=device)
+        # torch.empty: nothing is queued on torch's stream for these buffers, so the renderer's own (non-blocking)
+        # stream, which rtx_pack_tiles writes `send` on, cannot be overtaken by a late zero-fill
+        self.send = torch.empty(n, dtype=torch.float32, device=device)
         recv_device = "cpu" if host_staging else device
-        self.recv = [torch.zeros(n, dtype=torch.float32, device=recv_device) for _ in range(world_size)] if rank == 0 else None
-        self.stage = torch.zeros(n, dtype=torch.float32, device=device) if (host_staging and rank == 0) else None
+        self.recv = [torch.empty(n, dtype=torch.float32, device=recv_device) for _ in range(world_size)] if rank == 0 else None
+        self.stage = torch.empty(n, dtype=torch.float32, device=device) if (host_staging and rank == 0) else None
+        self.send_host = torch.empty(n, dtype=torch.float32, pin_memory=True) if host_staging else None
+        torch.cuda.synchronize(device)
 
     def gather(self):
+        """One exchange: every rank's tiles to rank 0's resident framebuffer. The device-tensor (nccl = RCCL) path has
+        only ever run with one rank on this pool (no multi-GPU box was available to the build); the two-rank tests use
+        host staging over gloo."""
         import torch
         import torch.distributed as dist
         self.shader.pack_tiles(self.send.data_ptr())          # synchronises the renderer's stream
         if self.host_staging:
-            dist.gather(self.send.cpu(), self.recv, dst=0, group=self.group)
+            self.send_host.copy_(self.send)
+            torch.cuda.current_stream().synchronize()
+            dist.gather(self.send_host, self.recv, dst=0, group=self.group)
         else:
             dist.gather(self.send, self.recv, dst=0, group=self.group)
         if self.rank == 0:

@@ -89,6 +89,11 @@ class HIPShader:
         self._chk(self._L.rtx_download_pixels(self._h, px.ctypes.data), "rtx_download_pixels")
         return px
 
+    def download_into(self, pixels):
+        """rtx_download_pixels into a caller-owned array (no allocation on the way)."""
+        assert pixels.dtype == np.float32 and pixels.flags.c_contiguous and pixels.size == self.width * self.height * 4
+        self._chk(self._L.rtx_download_pixels(self._h, pixels.ctypes.data), "rtx_download_pixels")
+
     def upload(self, pixels):
         px = np.ascontiguousarray(pixels, dtype=np.float32)
         self._chk(self._L.rtx_upload_pixels(self._h, px.ctypes.data), "rtx_upload_pixels")

@@ -6,7 +6,9 @@ after the first shade of a frame, found by walking the dispatches in order) — 
 average duration and the per-launch average of every collected counter, plus derived ratios.
 GRBM_GUI_ACTIVE arrives summed over the 8 XCDs and is divided by 8 (it is a clock).
 
-usage: python scripts/pmc_summary.py gpurun_out/prof_<tag> [summary.json [traffic.json workload]]
+usage: python scripts/pmc_summary.py gpurun_out/prof_<tag> [summary.json [traffic.json workload:traversal]]
+(traffic.json is stamped with the digest of raytracer_amd/csrc/*.h,*.hip it was measured with; bench.py emits
+`roofline.traffic` only while that digest matches the source it runs)
 """
 import csv, glob, json, os, sys
 from collections import defaultdict
@@ -27,7 +29,7 @@ class BounceNamer:
         if k.startswith("k_primary"):
             self.trace, self.shade = 0, 0
             return k
-        if k.startswith("k_trace_refill"):
+        if k.startswith("k_trace_refill") or k.startswith("k_trace_q"):
             return f"{k}#b{k[k.index('<') + 1:k.index('>')].split(',')[1].strip()}"     # the bounce is a template argument
         if k.startswith("k_trace<"):
             self.trace += 1
@@ -107,8 +109,11 @@ def main():
                  "k_trace1": [k for k in out if k.startswith("k_trace") and counting(k) and k.endswith("#b1")],
                  "k_trace2": [k for k in out if k.startswith("k_trace") and counting(k) and k.endswith("#b2")],
                  "k_trace3": [k for k in out if k.startswith("k_trace") and counting(k) and k.endswith("#b3")]}
-        t = {"_note": "HBM-side bytes per launch = 2 x FETCH_SIZE KiB x 1024 + WRITE_SIZE KiB x 1024, separate rocprofv3 --pmc passes over "
-                      "`python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline` (scripts/prof_round.sh), launches of bench.py's roofline pass; the x2 is the guide's gfx950 "
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from bench import csrc_digest
+        t = {"csrc_sha256_16": csrc_digest(),
+             "_note": "HBM-side bytes per launch = 2 x FETCH_SIZE KiB x 1024 + WRITE_SIZE KiB x 1024, separate rocprofv3 --pmc passes over "
+                      "`python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-extras` (scripts/prof_round.sh), launches of bench.py's roofline pass; the x2 is the guide's gfx950 "
                       "correction (128-B requests tallied at 64 B), calibrated for this access pattern with tools/gather_ceiling (7 x 16 B "
                       "from one scattered 128-B line per lane: one TCC_EA0_RDREQ and 64 B of FETCH_SIZE per line); Infinity-Cache hits "
                       "are counted, not excluded",

@@ -3,9 +3,10 @@
 # $1 = output tag (gpurun_out/prof_$1). Kernel trace first, then one --pmc pass per counter group.
 set -e
 export TMPDIR=/tmp
+export GPU_MAX_HW_QUEUES=16     # what bench.py sets for itself; exported so that the profiler's own HIP initialisation sees it too
 OUT=gpurun_out/prof_$1
 mkdir -p $OUT
-B="python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline"
+B="python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-extras ${RTX_PROF_ARGS:-}"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $B > $OUT/trace.log 2>&1
 echo trace done
 timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $B > $OUT/pmc_fetch.log 2>&1
