@@ -149,6 +149,13 @@ typedef struct RtxConfig {
                               6 with GPU_MAX_HW_QUEUES=8, 14 with 16 (an environment variable HIP reads at
                               start-up); at most 16. Each frame in flight holds its own ray queues and path
                               state: about 125 B per pixel of this rank's tiles */
+    int32_t numDevices;    /* > 1: a DEVICE GROUP in this one process — devices[0..numDevices) each render the tiles   */
+    int32_t devices[8];    /* of rank i of numDevices (scene flattened once, replicated), and every call that delivers
+                              a frame (rtx_render with pixels, rtx_download_pixels) first gathers the members' tiles
+                              into devices[0]'s framebuffer with one peer copy each (xGMI). The returned handle stands
+                              for the whole group, so IFrameRender::Render(Color*) drives up to 8 GPUs with the
+                              reference's Main.cpp untouched. rank/worldSize must be 0/1 then. The same ordinal may
+                              appear twice (rehearsal on one GPU). 0 or 1: one device, `device`. */
 } RtxConfig;
 
 typedef struct RtxCounters {
@@ -187,6 +194,8 @@ typedef struct RtxInfo {
     double   sliverFraction;   /* triangles with longest edge^2 / (2 area) > 32 */
     uint64_t deviceBytes;      /* device memory held by this renderer */
     double   createSeconds[4]; /* validate + walk boxes, own-tree build, record emission, upload + allocation */
+    int32_t  devices;          /* members of the device group this handle stands for (1: a single renderer) */
+    int32_t  _pad;
 } RtxInfo;
 
 typedef struct RtxRenderer RtxRenderer;

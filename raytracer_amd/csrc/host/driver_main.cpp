@@ -1,12 +1,16 @@
 // rtx_run — headless driver for the HIP backend with the reference's flags
 // (src/Configurator.cpp:78-142): -L <scn> -w <px> -h <px> -B -F <frames> -O,
 // plus -o <file.pfm|file.bmp> to write the frame (the reference's -F mode never
-// writes one, src/Main.cpp:46-54), -g <gamma> for the BMP, and -N <triangles> for the synthetic scene.
+// writes one, src/Main.cpp:46-54), -g <gamma> for the BMP, -N <triangles> for the synthetic scene, and
+// -G <n> to render on a group of n GPUs of this process (RtxConfig.numDevices; ordinals wrap around the
+// devices present, so -G 2 also runs on a one-GPU box, as two members on the same device).
 // It replays src/Main.cpp:13-54 (bounded frames) and :56-82 (orbit camera, run
 // headlessly for -F frames) with HIPShader in the place of ThreadedShader.
 // Per-frame timing goes to Performance_log.csv in the reference's format
 // ("fps;frametime(ms)", src/PerformanceMonitor.cpp:10,27).
 #include "hip_shader.h"
+
+#include <hip/hip_runtime_api.h>
 
 #include <algorithm>
 #include <chrono>
@@ -53,7 +57,7 @@ static void write_bmp(const char* path, const std::vector<Color>& px, uint32_t w
 
 int main(int argc, char** argv) {
     const char* scenePath = nullptr; const char* outPath = nullptr;
-    int w = 1000, h = 1000, frames = 1; bool bvh = false, orbit = false; long long synth = 0; float gamma = 0.0f;
+    int w = 1000, h = 1000, frames = 1, gpus = 1; bool bvh = false, orbit = false; long long synth = 0; float gamma = 0.0f;
     for (int i = 1; i < argc; ++i) {
         const char* a = argv[i];
         if (a[0] != '-' || !a[1] || a[2]) { fprintf(stderr, "Unknown argument: %s\n", a); return -1; }
@@ -72,8 +76,9 @@ int main(int argc, char** argv) {
             case 'o': outPath = val("an output file"); break;
             case 'N': synth = atoll(val("a triangle count")); break;
             case 'g': gamma = (float)atof(val("a gamma value")); break;
+            case 'G': gpus = std::min(8, std::max(1, atoi(val("a number of GPUs")))); break;
             case 'V': case 'S': break;
-            case 'H': printf("Usage: rtx_run [-L scene.scn | -N triangles] [-w W] [-h H] [-B] [-F frames] [-O] [-o out.pfm|out.bmp] [-g gamma (BMP only, e.g. 2.2)]\n"); return 0;
+            case 'H': printf("Usage: rtx_run [-L scene.scn | -N triangles] [-w W] [-h H] [-B] [-F frames] [-O] [-o out.pfm|out.bmp] [-g gamma (BMP only, e.g. 2.2)] [-G gpus]\n"); return 0;
             default: fprintf(stderr, "Unknown argument: %s\n", a); return -1;
         }
     }
@@ -102,7 +107,15 @@ int main(int argc, char** argv) {
     printf("Resolution : %d x %d\n", context.width, context.height);
     std::vector<Color> pixels((size_t)context.width * context.height, Color{0, 0, 0, 0});   // src/WindowManager.cpp:26-27
 
-    IFrameRender* service = new HIPShader(&context);
+    RtxConfig cfg; memset(&cfg, 0, sizeof(cfg));
+    if (gpus > 1) {
+        int present = 0;
+        if (hipGetDeviceCount(&present) != hipSuccess || present < 1) { fprintf(stderr, "no GPU\n"); return -1; }
+        cfg.numDevices = gpus;
+        for (int i = 0; i < gpus; ++i) cfg.devices[i] = i % present;
+        printf("Device group : %d members on %d GPU(s)\n", gpus, std::min(gpus, present));
+    }
+    IFrameRender* service = new HIPShader(&context, &cfg);
     FILE* csv = fopen("Performance_log.csv", "w");
     if (csv) fprintf(csv, "fps;frametime(ms)\n");
     float yaw = 0.0f, pitch = 0.0f;

@@ -42,6 +42,7 @@ static const int kMaxDevices = 64;
 static unsigned char* g_scratch[kMaxDevices] = {};      // per device: address of that device's copy of scratch[]
 static std::mutex g_scratchMutex;
 
+struct RtxRenderer;
 static const int kRing = 32;      // frames whose timing events are kept; a frame's timing is read kLag frames later
 static const int kLag = 16;
 static const int kEvents = 10;    // start + one per kernel (8) + end
@@ -121,6 +122,13 @@ struct RtxRenderer {
     int ringPos = 0;
     RtxCounters totals{};
     RtxInfo info{};
+    // device group (rtx_create with numDevices > 1): the leader (member 0) lists the other members; each of those holds
+    // a packed-tile buffer on its own device and one on the leader's
+    std::vector<RtxRenderer*> peers;
+    RtxRenderer* leader = nullptr;
+    float* dPackedOwn = nullptr;
+    float* dPackedAtLeader = nullptr;
+    int leaderDevice = -1;
     std::vector<float> hostStage;   // D2H staging for worldSize > 1
     char* hStage = nullptr;         // page-locked staging for delivering the frame to a (pageable) host array
     size_t hStageBytes = 0;
@@ -619,6 +627,8 @@ int check_camera(const RtxCamera* cam) {
 
 } // namespace
 
+static int build_renderer(const RtxSceneDesc* scene, const RtxConfig& cfg, const Flat& flat, bool useBVH, PhaseClock& createClock, RtxRenderer** out);
+
 // ---------------------------------------------------------------------------------
 extern "C" {
 
@@ -627,7 +637,11 @@ const char* rtx_version(void) { return "raytracer_amd HIP backend 0.1 (gfx950)";
 
 void rtx_destroy(RtxRenderer* r) {
     if (!r) return;
+    for (RtxRenderer* m : r->peers) { m->leader = nullptr; rtx_destroy(m); }
+    r->peers.clear();
     hipSetDevice(r->device);
+    if (r->dPackedOwn) hipFree(r->dPackedOwn);
+    if (r->dPackedAtLeader && r->leaderDevice >= 0) { hipSetDevice(r->leaderDevice); hipFree(r->dPackedAtLeader); hipSetDevice(r->device); }
     for (auto& c : r->ctx) {
         if (c.stream) hipStreamSynchronize(c.stream);
         void* own[] = {c.dRqO[0], c.dRqO[1], c.dRqD[0], c.dRqD[1], c.dHitT, c.dHitLeaf, c.dLight, c.dAcc, c.dSeeds, c.dCtrl, c.dSlow, c.dSpill};
@@ -672,6 +686,14 @@ int rtx_create(const RtxSceneDesc* scene, const RtxConfig* cfgIn, RtxRenderer** 
             (uint64_t)t.offset + (uint64_t)t.width * (uint64_t)t.height > scene->numTexels)
             return fail("texture " + std::to_string(i) + ": extent outside textureData (or wider than 4096)");
     }
+    if (cfg.numDevices > 1) {
+        if (cfg.numDevices > 8) return fail("RtxConfig.numDevices: at most 8");
+        if (cfg.worldSize != 1) return fail("a device group (numDevices > 1) cannot also be one rank of a process group (worldSize > 1)");
+        int count = 0;
+        HIP_TRY(hipGetDeviceCount(&count));
+        for (int i = 0; i < cfg.numDevices; ++i)
+            if (cfg.devices[i] < 0 || cfg.devices[i] >= count) return fail("RtxConfig.devices[" + std::to_string(i) + "]: no such device");
+    }
     // src/ThreadedShader.cpp:15-19
     const bool useBVH = scene->useBVH && scene->numBoxes > 0;
     if (useBVH && !scene->boxes) return fail("boxes is NULL");
@@ -686,6 +708,36 @@ int rtx_create(const RtxSceneDesc* scene, const RtxConfig* cfgIn, RtxRenderer** 
     createClock.lap("flatten");
     if (useBVH && flat.maxDepth > 62) return fail("BVH deeper than 62 levels is not supported (the reference's own stack holds 32)");
 
+    if (cfg.numDevices <= 1) return build_renderer(scene, cfg, flat, useBVH, createClock, out);
+
+    // Device group (single process, several GPUs): member i renders the tiles of rank i of numDevices on devices[i],
+    // all from the one flattened scene; member 0 is the handle the caller gets, and delivering a frame gathers the
+    // other members' tiles into its framebuffer (gather_group).
+    std::vector<RtxRenderer*> members;
+    for (int i = 0; i < cfg.numDevices; ++i) {
+        RtxConfig c = cfg;
+        c.device = cfg.devices[i]; c.rank = i; c.worldSize = cfg.numDevices; c.numDevices = 0;
+        RtxRenderer* m = nullptr;
+        if (build_renderer(scene, c, flat, useBVH, createClock, &m)) { for (RtxRenderer* x : members) rtx_destroy(x); return 1; }
+        members.push_back(m);
+    }
+    RtxRenderer* lead = members[0];
+    lead->peers.assign(members.begin() + 1, members.end());
+    lead->info.devices = cfg.numDevices;
+    for (RtxRenderer* m : lead->peers) {
+        m->leader = lead; m->leaderDevice = lead->device;
+        const size_t bytes = (size_t)rtx_packed_floats(m, m->cfg.rank) * sizeof(float);
+        hipError_t e = hipSetDevice(m->device);
+        if (e == hipSuccess) e = hipMalloc((void**)&m->dPackedOwn, std::max<size_t>(bytes, 64));
+        if (e == hipSuccess) e = hipSetDevice(lead->device);
+        if (e == hipSuccess) e = hipMalloc((void**)&m->dPackedAtLeader, std::max<size_t>(bytes, 64));
+        if (e != hipSuccess) { fail(std::string("device group buffers: ") + hipGetErrorString(e)); rtx_destroy(lead); return 1; }
+    }
+    *out = lead;
+    return 0;
+}
+
+static int build_renderer(const RtxSceneDesc* scene, const RtxConfig& cfg, const Flat& flat, bool useBVH, PhaseClock& createClock, RtxRenderer** out) {
     RtxRenderer* r = new RtxRenderer();
     memset(r->ev, 0, sizeof(r->ev));
     r->cfg = cfg; r->device = cfg.device;
@@ -843,6 +895,7 @@ int rtx_create(const RtxSceneDesc* scene, const RtxConfig* cfgIn, RtxRenderer** 
         RtxInfo& in = r->info;
         in.traversal = r->linear ? RTX_TRAVERSE_EXACT : (culled ? (std::isinf(r->sc.cullSlack) ? RTX_TRAVERSE_WIDE : RTX_TRAVERSE_CULLED) : RTX_TRAVERSE_EXACT);
         in.linear = r->linear ? 1 : 0;
+        in.devices = 1;
         in.bigNodes = (r->mode == RTX_MODE_CULLED_BIG || r->mode == RTX_MODE_WIDEQ_BIG) ? 1 : 0;
         in.cullSlack = culled ? r->sc.cullSlack : INFINITY;
         in.framesInFlight = depth; in.framesPerBatch = r->batch; in.hwQueues = hwQueues;
@@ -1007,9 +1060,38 @@ static int copy_out(RtxRenderer* r, float* pixels) {
     return 0;
 }
 
+// Device group: every member's tiles into the leader's resident framebuffer. Packs on each member's device, one
+// peer copy per member (xGMI between GPUs), unpack on the leader. Once per delivered frame.
+static int gather_group(RtxRenderer* r) {
+    if (r->peers.empty()) return 0;
+    if (sync_all(r)) return 1;
+    for (RtxRenderer* m : r->peers) if (rtx_pack_tiles(m, m->dPackedOwn)) return 1;          // completes m's queued frames first
+    for (RtxRenderer* m : r->peers) {
+        const size_t bytes = (size_t)rtx_packed_floats(m, m->cfg.rank) * sizeof(float);
+        if (bytes) HIP_TRY(hipMemcpyPeer(m->dPackedAtLeader, r->device, m->dPackedOwn, m->device, bytes));
+    }
+    HIP_TRY(hipSetDevice(r->device));
+    for (RtxRenderer* m : r->peers) if (rtx_unpack_tiles(r, m->dPackedAtLeader, m->cfg.rank)) return 1;
+    return 0;
+}
+
+static int render_one(RtxRenderer* r, const RtxCamera* camera, uint32_t frameCounter, float* pixels_rgba);
+
 int rtx_render(RtxRenderer* r, const RtxCamera* camera, uint32_t frameCounter, float* pixels_rgba) {
     if (!r) return fail("renderer is NULL");
     if (check_camera(camera)) return 1;
+    if (r->leader) return fail("this renderer is a member of a device group: call its leader");
+    if (r->peers.empty()) return render_one(r, camera, frameCounter, pixels_rgba);
+    // device group: the frame is queued on every member (their launches run side by side on their devices) ...
+    if (render_one(r, camera, frameCounter, nullptr)) return 1;
+    for (RtxRenderer* m : r->peers) if (render_one(m, camera, frameCounter, nullptr)) return 1;
+    if (!pixels_rgba) return 0;
+    // ... and delivered from the leader after one gather
+    if (gather_group(r)) return 1;
+    return fb_to_host(r, pixels_rgba, (size_t)r->width * r->height * sizeof(float4));
+}
+
+static int render_one(RtxRenderer* r, const RtxCamera* camera, uint32_t frameCounter, float* pixels_rgba) {
     if (!pixels_rgba && r->batch > 1) {
         // nothing has to be delivered yet: collect the frame; a full batch is rendered by one set of launches
         r->queued.emplace_back(*camera, frameCounter);
@@ -1021,9 +1103,29 @@ int rtx_render(RtxRenderer* r, const RtxCamera* camera, uint32_t frameCounter, f
     return 0;
 }
 
+static int primary_hits_one(RtxRenderer* r, const RtxCamera* camera, uint32_t frameCounter, int32_t* objectIDs);
+
 int rtx_primary_hits(RtxRenderer* r, const RtxCamera* camera, uint32_t frameCounter, int32_t* objectIDs) {
     if (!r || !objectIDs) return fail("NULL argument");
     if (check_camera(camera)) return 1;
+    if (r->peers.empty()) return primary_hits_one(r, camera, frameCounter, objectIDs);
+    // device group: every member answers for its own tiles
+    if (primary_hits_one(r, camera, frameCounter, objectIDs)) return 1;
+    std::vector<int32_t> part((size_t)r->width * r->height);
+    for (RtxRenderer* m : r->peers) {
+        if (primary_hits_one(m, camera, frameCounter, part.data())) return 1;
+        for (const int2& t : m->localTiles) {
+            const int w = std::min(m->tileW, (int)m->width - t.x), h = std::min(m->tileH, (int)m->height - t.y);
+            for (int y = 0; y < h; ++y) {
+                const size_t off = (size_t)(t.y + y) * m->width + t.x;
+                memcpy(objectIDs + off, part.data() + off, (size_t)w * sizeof(int32_t));
+            }
+        }
+    }
+    return 0;
+}
+
+static int primary_hits_one(RtxRenderer* r, const RtxCamera* camera, uint32_t frameCounter, int32_t* objectIDs) {
     if (render_frame(r, camera, frameCounter, true)) return 1;
     const size_t npx = (size_t)r->width * r->height;
     int* dIds = nullptr;
@@ -1131,6 +1233,7 @@ int rtx_trace_rays_noalloc(RtxRenderer* r, const float* d_origins, const float* 
 
 int rtx_upload_pixels(RtxRenderer* r, const float* pixels) {
     if (!r || !pixels) return fail("NULL argument");
+    for (RtxRenderer* m : r->peers) if (rtx_upload_pixels(m, pixels)) return 1;      // each member reads its own tiles of it
     HIP_TRY(hipSetDevice(r->device));
     if (sync_all(r)) return 1;
     HIP_TRY(hipMemcpyAsync(r->dFb, pixels, (size_t)r->width * r->height * sizeof(float4), hipMemcpyHostToDevice, r->stream));
@@ -1139,6 +1242,7 @@ int rtx_upload_pixels(RtxRenderer* r, const float* pixels) {
 }
 int rtx_download_pixels(RtxRenderer* r, float* pixels) {
     if (!r || !pixels) return fail("NULL argument");
+    if (gather_group(r)) return 1;
     HIP_TRY(hipSetDevice(r->device));
     if (sync_all(r)) return 1;
     const size_t bytes = (size_t)r->width * r->height * sizeof(float4);
@@ -1146,6 +1250,7 @@ int rtx_download_pixels(RtxRenderer* r, float* pixels) {
 }
 int rtx_clear_pixels(RtxRenderer* r) {
     if (!r) return fail("NULL argument");
+    for (RtxRenderer* m : r->peers) if (rtx_clear_pixels(m)) return 1;
     HIP_TRY(hipSetDevice(r->device));
     if (sync_all(r)) return 1;
     HIP_TRY(hipMemsetAsync(r->dFb, 0, (size_t)r->width * r->height * sizeof(float4), r->stream));
@@ -1177,11 +1282,25 @@ int rtx_get_counters(RtxRenderer* r, RtxCounters* out) {
         c.rays += c.raysPerBounce[b];
     }
     for (int b = 0; b < 4; ++b) { c.innerVisits[b] = st[RTX_STAT_INNER(b)]; c.leafTests[b] = st[RTX_STAT_LEAF(b)]; c.wavePasses[b] = st[RTX_STAT_PASSES(b)]; }
+    // device group: work adds up over the members, device times are those of the slowest member
+    for (RtxRenderer* m : r->peers) {
+        RtxCounters p;
+        if (rtx_get_counters(m, &p)) return 1;
+        c.rays += p.rays;
+        for (int b = 0; b < 4; ++b) {
+            c.raysPerBounce[b] += p.raysPerBounce[b]; c.hitsPerBounce[b] += p.hitsPerBounce[b];
+            c.innerVisits[b] += p.innerVisits[b]; c.leafTests[b] += p.leafTests[b]; c.wavePasses[b] += p.wavePasses[b];
+        }
+        c.lastFrameMs = std::max(c.lastFrameMs, p.lastFrameMs); c.lastTraceMs = std::max(c.lastTraceMs, p.lastTraceMs);
+        c.lastShadeMs = std::max(c.lastShadeMs, p.lastShadeMs); c.totalMs = std::max(c.totalMs, p.totalMs);
+        for (int k = 0; k < 8; ++k) c.kernelMs[k] = std::max(c.kernelMs[k], p.kernelMs[k]);
+    }
     *out = c;
     return 0;
 }
 int rtx_reset_counters(RtxRenderer* r) {
     if (!r) return fail("NULL argument");
+    for (RtxRenderer* m : r->peers) if (rtx_reset_counters(m)) return 1;
     HIP_TRY(hipSetDevice(r->device));
     if (sync_all(r)) return 1;
     for (int i = 0; i < kRing; ++i) finish_timing(r, i);
@@ -1193,7 +1312,12 @@ int rtx_reset_counters(RtxRenderer* r) {
 
 void* rtx_framebuffer_device_ptr(RtxRenderer* r) { return r ? (void*)r->dFb : nullptr; }
 void* rtx_stream(RtxRenderer* r) { return r ? (void*)r->stream : nullptr; }
-uint64_t rtx_local_pixel_count(RtxRenderer* r) { return r ? r->localPixels : 0; }
+uint64_t rtx_local_pixel_count(RtxRenderer* r) {
+    if (!r) return 0;
+    uint64_t n = r->localPixels;
+    for (RtxRenderer* m : r->peers) n += m->localPixels;       // a device group owns all its members' tiles
+    return n;
+}
 uint32_t rtx_local_tile_count(RtxRenderer* r) { return r ? (uint32_t)r->localTiles.size() : 0; }
 uint64_t rtx_packed_floats(RtxRenderer* r, int32_t rank) {
     if (!r || rank < 0 || rank >= r->cfg.worldSize) return 0;
@@ -1201,6 +1325,7 @@ uint64_t rtx_packed_floats(RtxRenderer* r, int32_t rank) {
 }
 int rtx_pack_tiles(RtxRenderer* r, void* d_packed) {
     if (!r || !d_packed) return fail("NULL argument");
+    if (!r->peers.empty()) return fail("rtx_pack_tiles: a device group delivers whole frames (it is not a rank of a process group)");
     HIP_TRY(hipSetDevice(r->device));
     if (sync_all(r)) return 1;
     const uint64_t total = (uint64_t)r->localTiles.size() * r->tileW * r->tileH;
