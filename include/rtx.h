@@ -251,6 +251,15 @@ int rtx_upload_pixels(RtxRenderer* r, const float* pixels_rgba);
 int rtx_download_pixels(RtxRenderer* r, float* pixels_rgba);
 int rtx_clear_pixels(RtxRenderer* r);
 
+/* Present path. Replaces the pixel hand-over of WindowManager::UpdateWindow (src/WindowManager.cpp:160-166:
+ * glTexSubImage2D(..., GL_RGBA, GL_FLOAT, pixels) into a GL_RGBA texture, :18 — GL clamps to [0,1] and rounds to 8
+ * bits): the resident running mean is converted on the device — clamp, optional display gamma (context->gamma,
+ * src/RenderingContext.h:48; <= 0: none; alpha is never gamma-corrected), round(x * 255) — and delivered as
+ * width*height RGBA8 words (R in the low byte), 4 bytes per pixel instead of 16 over PCIe. The caller uploads it with
+ * GL_RGBA / GL_UNSIGNED_BYTE, or writes it out as the screenshot of WindowManager::DumpContent (:212-259). Completes
+ * all queued frames first (and gathers a device group), like rtx_download_pixels. */
+int rtx_present_rgba8(RtxRenderer* r, float gamma, uint8_t* rgba8);
+
 int  rtx_get_info(RtxRenderer* r, RtxInfo* out);
 int  rtx_get_counters(RtxRenderer* r, RtxCounters* out);
 int  rtx_reset_counters(RtxRenderer* r);

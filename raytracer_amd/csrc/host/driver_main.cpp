@@ -2,6 +2,8 @@
 // (src/Configurator.cpp:78-142): -L <scn> -w <px> -h <px> -B -F <frames> -O,
 // plus -o <file.pfm|file.bmp> to write the frame (the reference's -F mode never
 // writes one, src/Main.cpp:46-54), -g <gamma> for the BMP, -N <triangles> for the synthetic scene, and
+// -P to run the windowed loop's hand-over headlessly (src/WindowManager.cpp:160-187: Render, then the frame goes to the
+// display as 8-bit RGBA — rtx_present_rgba8 with context->gamma — every frame; -o x.bmp then writes that 8-bit image),
 // -G <n> to render on a group of n GPUs of this process (RtxConfig.numDevices; ordinals wrap around the
 // devices present, so -G 2 also runs on a one-GPU box, as two members on the same device).
 // It replays src/Main.cpp:13-54 (bounded frames) and :56-82 (orbit camera, run
@@ -57,7 +59,7 @@ static void write_bmp(const char* path, const std::vector<Color>& px, uint32_t w
 
 int main(int argc, char** argv) {
     const char* scenePath = nullptr; const char* outPath = nullptr;
-    int w = 1000, h = 1000, frames = 1, gpus = 1; bool bvh = false, orbit = false; long long synth = 0; float gamma = 0.0f;
+    int w = 1000, h = 1000, frames = 1, gpus = 1; bool bvh = false, orbit = false, present = false; long long synth = 0; float gamma = 0.0f;
     for (int i = 1; i < argc; ++i) {
         const char* a = argv[i];
         if (a[0] != '-' || !a[1] || a[2]) { fprintf(stderr, "Unknown argument: %s\n", a); return -1; }
@@ -77,8 +79,9 @@ int main(int argc, char** argv) {
             case 'N': synth = atoll(val("a triangle count")); break;
             case 'g': gamma = (float)atof(val("a gamma value")); break;
             case 'G': gpus = std::min(8, std::max(1, atoi(val("a number of GPUs")))); break;
+            case 'P': present = true; break;
             case 'V': case 'S': break;
-            case 'H': printf("Usage: rtx_run [-L scene.scn | -N triangles] [-w W] [-h H] [-B] [-F frames] [-O] [-o out.pfm|out.bmp] [-g gamma (BMP only, e.g. 2.2)] [-G gpus]\n"); return 0;
+            case 'H': printf("Usage: rtx_run [-L scene.scn | -N triangles] [-w W] [-h H] [-B] [-F frames] [-O] [-o out.pfm|out.bmp] [-g gamma (BMP only, e.g. 2.2)] [-G gpus] [-P]\n"); return 0;
             default: fprintf(stderr, "Unknown argument: %s\n", a); return -1;
         }
     }
@@ -115,6 +118,7 @@ int main(int argc, char** argv) {
         for (int i = 0; i < gpus; ++i) cfg.devices[i] = i % present;
         printf("Device group : %d members on %d GPU(s)\n", gpus, std::min(gpus, present));
     }
+    std::vector<uint32_t> rgba8(present ? (size_t)context.width * context.height : 0);
     IFrameRender* service = new HIPShader(&context, &cfg);
     FILE* csv = fopen("Performance_log.csv", "w");
     if (csv) fprintf(csv, "fps;frametime(ms)\n");
@@ -128,7 +132,17 @@ int main(int argc, char** argv) {
             yaw = (yaw >= 360.0f) * (yaw - 360.0f) + (yaw < 360.0f) * yaw; yaw += 0.1f;
             pitch = (pitch >= 360.0f) * (pitch - 360.0f) + (pitch < 360.0f) * pitch; pitch += 0.1f;
         }
-        service->Render(pixels.data());                     // src/WindowManager.cpp:156
+        if (present) {
+            // UpdateWindow (src/WindowManager.cpp:160-166) without the window: the frame stays on the device and
+            // what the texture upload needs — 8-bit RGBA — comes back
+            RtxRenderer* h = static_cast<HIPShader*>(service)->handle();
+            if (rtx_render(h, &context.camera, context.frameCounter, nullptr) != 0 ||
+                rtx_present_rgba8(h, gamma > 0 ? gamma : context.gamma, (uint8_t*)rgba8.data()) != 0) {
+                fprintf(stderr, "present: %s\n", rtx_last_error()); return -1;
+            }
+        } else {
+            service->Render(pixels.data());                 // src/WindowManager.cpp:156
+        }
         context.frameCounter++;                             // :157
         auto t1 = std::chrono::steady_clock::now();
         double dt = std::chrono::duration<double>(t1 - t0).count(); t0 = t1; total += dt;
@@ -139,7 +153,24 @@ int main(int argc, char** argv) {
     rtx_get_counters(static_cast<HIPShader*>(service)->handle(), &c);
     printf("%u frames, %.3f ms/frame wall (incl. host copy), %.3f ms/frame device, %.1f Mrays/s (device)\n",
            context.numBoundedFrames, total / frames * 1e3, c.totalMs / frames, c.rays / (c.totalMs * 1e-3) / 1e6);
-    if (outPath) {
+    if (outPath && present) {
+        // the displayed image, as a 32-bit BMP (what WindowManager::DumpContent writes, with a correct header)
+        FILE* f = fopen(outPath, "wb");
+        if (f) {
+            const uint32_t w = context.width, h = context.height, size = 54 + w * h * 4;
+            unsigned char hd[54] = {'B', 'M'};
+            auto put32 = [&](int off, uint32_t v) { memcpy(hd + off, &v, 4); };
+            put32(2, size); put32(10, 54); put32(14, 40); put32(18, w); put32(22, h);
+            hd[26] = 1; hd[28] = 32; put32(34, w * h * 4);
+            fwrite(hd, 1, 54, f);
+            for (size_t i = 0; i < rgba8.size(); ++i) {                 // RGBA words -> BGRA bytes
+                const uint32_t p = rgba8[i];
+                const unsigned char px4[4] = {(unsigned char)(p >> 16), (unsigned char)(p >> 8), (unsigned char)p, (unsigned char)(p >> 24)};
+                fwrite(px4, 1, 4, f);
+            }
+            fclose(f);
+        }
+    } else if (outPath) {
         const size_t n = strlen(outPath);
         if (n > 4 && strcmp(outPath + n - 4, ".bmp") == 0) write_bmp(outPath, pixels, context.width, context.height, gamma);
         else write_pfm(outPath, pixels, context.width, context.height);

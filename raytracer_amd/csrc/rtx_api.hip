@@ -129,6 +129,7 @@ struct RtxRenderer {
     float* dPackedOwn = nullptr;
     float* dPackedAtLeader = nullptr;
     int leaderDevice = -1;
+    uint32_t* dPresent = nullptr;    // rtx_present_rgba8: the 8-bit image on the device (allocated on first use)
     std::vector<float> hostStage;   // D2H staging for worldSize > 1
     char* hStage = nullptr;         // page-locked staging for delivering the frame to a (pageable) host array
     size_t hStageBytes = 0;
@@ -641,6 +642,7 @@ void rtx_destroy(RtxRenderer* r) {
     r->peers.clear();
     hipSetDevice(r->device);
     if (r->dPackedOwn) hipFree(r->dPackedOwn);
+    if (r->dPresent) hipFree(r->dPresent);
     if (r->dPackedAtLeader && r->leaderDevice >= 0) { hipSetDevice(r->leaderDevice); hipFree(r->dPackedAtLeader); hipSetDevice(r->device); }
     for (auto& c : r->ctx) {
         if (c.stream) hipStreamSynchronize(c.stream);
@@ -1004,14 +1006,19 @@ static int render_frame(RtxRenderer* r, const RtxCamera* cam, uint32_t fc, bool 
 }
 
 // device framebuffer -> host array
-static int fb_to_host(RtxRenderer* r, float* pixels, size_t bytes) {
-    char* dst = (char*)pixels; const char* src = (const char*)r->dFb;
+static int dev_to_host(RtxRenderer* r, const void* devSrc, void* hostDst, size_t bytes);
+static int fb_to_host(RtxRenderer* r, float* pixels, size_t bytes) { return dev_to_host(r, r->dFb, pixels, bytes); }
+
+// device array of this renderer -> caller's (pageable) host array
+static int dev_to_host(RtxRenderer* r, const void* devSrc, void* hostDst, size_t bytes) {
+    char* dst = (char*)hostDst; const char* src = (const char*)devSrc;
     if (bytes >= ((size_t)8 << 20) && !getenv("RTX_PLAIN_COPY")) {
         // The caller's array is ordinary pageable memory (page-locking it per call costs more than the copy, and
         // caching a registration across calls would outlive the array): copy through a page-locked staging buffer
         // of the renderer in 8 MiB pieces and let four host threads move each piece on as soon as it has landed.
         // 133.7 MB at 4K: 8.5 ms through the runtime's pageable path, 3.0 ms this way.
         const size_t piece = (size_t)8 << 20, n = (bytes + piece - 1) / piece;
+        if (r->hStage && r->hStageBytes < bytes) { hipHostFree(r->hStage); r->hStage = nullptr; }
         if (!r->hStage) { HIP_TRY(hipHostMalloc((void**)&r->hStage, bytes, hipHostMallocDefault)); r->hStageBytes = bytes; }
         while (r->stageEv.size() < n) { hipEvent_t e; HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming)); r->stageEv.push_back(e); }
         for (size_t k = 0; k < n; ++k) {
@@ -1248,6 +1255,19 @@ int rtx_download_pixels(RtxRenderer* r, float* pixels) {
     const size_t bytes = (size_t)r->width * r->height * sizeof(float4);
     return fb_to_host(r, pixels, bytes);
 }
+int rtx_present_rgba8(RtxRenderer* r, float gamma, uint8_t* rgba8) {
+    if (!r || !rgba8) return fail("NULL argument");
+    if (r->leader) return fail("this renderer is a member of a device group: call its leader");
+    if (gather_group(r)) return 1;
+    HIP_TRY(hipSetDevice(r->device));
+    if (sync_all(r)) return 1;
+    const uint32_t n = r->width * r->height;
+    if (!r->dPresent) HIP_TRY(hipMalloc((void**)&r->dPresent, (size_t)n * sizeof(uint32_t)));
+    hipLaunchKernelGGL(k_present_rgba8, dim3((n + 255u) / 256u), dim3(256), 0, r->stream, r->dFb, r->dPresent, n, gamma > 0.0f ? 1.0f / gamma : 0.0f);
+    HIP_TRY(hipGetLastError());
+    return dev_to_host(r, r->dPresent, rgba8, (size_t)n * sizeof(uint32_t));       // the staged copy of the float frame, a quarter of the bytes
+}
+
 int rtx_clear_pixels(RtxRenderer* r) {
     if (!r) return fail("NULL argument");
     for (RtxRenderer* m : r->peers) if (rtx_clear_pixels(m)) return 1;

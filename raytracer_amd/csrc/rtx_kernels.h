@@ -656,6 +656,25 @@ __global__ void k_stage_directions(const float4* __restrict__ in, float4* __rest
     out[q] = make_float4(d.x, d.y, d.z, 0.0f);
 }
 
+// ---- present ---------------------------------------------------------------------
+// The running mean as the 8-bit RGBA image a display path consumes (the reference uploads its float pixels into a
+// GL_RGBA texture, src/WindowManager.cpp:18,165, i.e. GL clamps to [0,1] and rounds to 8 bits; here that conversion
+// — with an optional display gamma, src/RenderingContext.h:48 — runs on the device and 4 bytes per pixel travel).
+__global__ void k_present_rgba8(const float4* __restrict__ fb, uint32_t* __restrict__ out, uint32_t n, float invGamma) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 c = fb[i];
+    float v[4] = {c.x, c.y, c.z, c.w};
+    uint32_t word = 0;
+    for (int k = 0; k < 4; ++k) {
+        float x = v[k];
+        x = x > 0.0f ? (x < 1.0f ? x : 1.0f) : 0.0f;                  // NaN -> 0
+        if (invGamma > 0.0f && k < 3) x = powf(x, invGamma);
+        word |= (uint32_t)(x * 255.0f + 0.5f) << (8 * k);             // GL's float -> unorm8: round(x * 255)
+    }
+    out[i] = word;
+}
+
 // ---- multi-GPU tile plumbing ----------------------------------------------------
 // packed layout: tile k of the rank at k*tileW*tileH float4, row-major inside the tile
 __global__ void k_pack_tiles(DevFrame fr, const int2* __restrict__ tiles, int numTiles, const float4* __restrict__ fb, float4* __restrict__ packed) {

@@ -98,6 +98,12 @@ class HIPShader:
         assert pixels.dtype == np.float32 and pixels.flags.c_contiguous and pixels.size == self.width * self.height * 4
         self._chk(self._L.rtx_download_pixels(self._h, pixels.ctypes.data), "rtx_download_pixels")
 
+    def present(self, gamma=0.0):
+        """rtx_present_rgba8: the running mean as an (h, w, 4) uint8 image (clamp, optional gamma, round to 8 bits on the device)."""
+        img = np.empty((self.height, self.width, 4), dtype=np.uint8)
+        self._chk(self._L.rtx_present_rgba8(self._h, C.c_float(gamma), img.ctypes.data), "rtx_present_rgba8")
+        return img
+
     def upload(self, pixels):
         px = np.ascontiguousarray(pixels, dtype=np.float32)
         self._chk(self._L.rtx_upload_pixels(self._h, px.ctypes.data), "rtx_upload_pixels")

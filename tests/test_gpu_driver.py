@@ -39,3 +39,38 @@ def test_headless_driver_renders_and_logs(tmp_path):
     bgr = np.frombuffer(raw[54:], dtype=np.uint8).reshape(128, 192, 3)
     want = np.clip(img, 0, 1) ** (1 / 2.2) * 255.0 + 0.5
     assert np.abs(bgr[:, :, ::-1].astype(np.float32) - np.floor(want)).max() <= 1.0
+
+
+def test_present_path_delivers_the_8bit_image(scene2):
+    """rtx_present_rgba8: what WindowManager::UpdateWindow hands to the display (src/WindowManager.cpp:160-166, a GL_RGBA
+    texture fed from the float pixels: clamp to [0,1], round to 8 bits), converted on the device."""
+    from raytracer_amd.renderer import HIPShader
+    r = HIPShader(scene2)
+    for f in range(3):
+        r.frame_counter = f
+        r.Render(None)
+    img = r.present()
+    px = r.download()
+    want = np.floor(np.clip(px, 0.0, 1.0) * np.float32(255.0) + np.float32(0.5)).astype(np.uint8)
+    assert img.shape == px.shape and (img == want).all()
+    g = r.present(gamma=2.2)
+    wantg = np.clip(px, 0.0, 1.0).astype(np.float64)
+    wantg[..., :3] = wantg[..., :3] ** (1 / 2.2)
+    assert np.abs(g.astype(np.int32) - np.floor(wantg * 255.0 + 0.5).astype(np.int32)).max() <= 1     # device powf vs numpy
+    assert (g[..., 3] == want[..., 3]).all()
+    # values outside [0,1] and NaN in the running mean
+    odd = np.zeros_like(px); odd[0, 0] = (-1.0, 2.0, np.nan, 0.5)
+    r.upload(odd)
+    assert tuple(r.present()[0, 0]) == (0, 255, 0, 128)
+    r.close()
+
+
+def test_headless_present_loop(tmp_path):
+    out = subprocess.run([RUN, "-N", "3000", "-w", "200", "-h", "130", "-B", "-F", "3", "-P", "-g", "2.2", "-o", "shot.bmp"],
+                         cwd=tmp_path, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    raw = (tmp_path / "shot.bmp").read_bytes()
+    assert raw[:2] == b"BM" and len(raw) == 54 + 192 * 128 * 4 and raw[28] == 32
+    assert len((tmp_path / "Performance_log.csv").read_text().splitlines()) == 4
+    bgra = np.frombuffer(raw[54:], dtype=np.uint8).reshape(128, 192, 4)
+    assert bgra[..., :3].std() > 2
