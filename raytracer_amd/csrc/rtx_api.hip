@@ -150,6 +150,13 @@ struct Flat {
     bool nested = true;                 // every box contains its children (precondition of the own tree)
     double sliverFraction = 0.0;        // triangles with longest edge^2 / (2 area) > 32 (or no area at all)
     double seconds[3] = {0, 0, 0};      // validate + walk, own-tree build, record emission
+    // BVH scenes: the records are emitted on the device (k_emit_leaf_records / k_emit_inner_records) from the caller's
+    // arrays; the host only plans them: for every leaf position its box and tie-break rank, and the index maps the
+    // reference-topology records need. (leaf / shade above are filled on the host only for the linear list.)
+    std::vector<int2> leafPlan;
+    std::vector<int32_t> slotOf, posOf;
+    size_t numLeaves = 0, numInner = 0;
+    bool deviceEmit = false;
 };
 
 inline float i2f(int32_t v) { float f; memcpy(&f, &v, 4); return f; }
@@ -196,7 +203,6 @@ void emit_leaf(const RtxObject& o, int32_t objectID, int32_t boxID, int32_t tieR
     shade[7] = make_float4(0, 0, 0, 0);
 }
 
-const int32_t kNoChild = (int32_t)0x80000000;   // never passes (see traverse_bvh)
 
 struct PhaseClock {
     const bool on = getenv("RTX_VERBOSE") != nullptr;
@@ -270,6 +276,7 @@ int flatten(const RtxSceneDesc& s, bool useBVH, bool wantFast, bool wantQuant, i
             for (uint64_t i = b; i < e; ++i) emit_leaf(s.objects[i], (int32_t)i, (int32_t)i, 0, nullptr, &f.leaf[i * 4], &f.shade[i * 8]);
         });
         f.rootRef = 0; f.maxDepth = 0;
+        f.numLeaves = (size_t)nObj; f.numInner = 0;
         return 0;
     }
     if (nBox > 0x7fffffffull) return fail("too many boxes");
@@ -441,9 +448,9 @@ int flatten(const RtxSceneDesc& s, bool useBVH, bool wantFast, bool wantQuant, i
         }
         f.seconds[1] += clock.lap("quantise nodes");
     }
-    // leaves in the new order; reference leaf index -> position
+    // leaves in the new order; reference leaf index -> position. The records themselves are written on the device.
     std::vector<int32_t> posOf((size_t)nLeaf);
-    f.leaf.resize((size_t)nLeaf * 4); f.shade.resize((size_t)nLeaf * 8);
+    f.leafPlan.resize((size_t)nLeaf);
     parallel_for((uint64_t)nLeaf, nthreads, [&](uint64_t p0, uint64_t p1) {
         for (uint64_t p = p0; p < p1; ++p) {
             posOf[order[p]] = (int32_t)p;
@@ -452,34 +459,14 @@ int flatten(const RtxSceneDesc& s, bool useBVH, bool wantFast, bool wantQuant, i
             const size_t k = order[p];
             const int32_t part = rankPart[k];
             const int32_t rank = (int32_t)std::max<int64_t>(0, partBase[(size_t)part] + (partCount[(size_t)part] - 1 - rankLocal[k]));
-            emit_leaf(s.objects[s.boxes[b].objectID], s.boxes[b].objectID, b, rank, &s.boxes[b], &f.leaf[(size_t)p * 4], &f.shade[(size_t)p * 8]);
+            f.leafPlan[p] = make_int2(b, rank);
         }
-    });
-    // the reference's own topology (used by RTX_TRAVERSE_EXACT and by lanes that cannot use the own tree)
-    f.inner.resize((size_t)nInner * 4);
-    parallel_for(nBox, nthreads, [&](uint64_t b0, uint64_t b1) {
-      for (uint64_t b = b0; b < b1; ++b) {
-        const RtxBoundingBox& box = s.boxes[b];
-        if (box.objectID != -1) continue;
-        float lo[2][3] = {{0, 0, 0}, {0, 0, 0}}, hi[2][3] = {{0, 0, 0}, {0, 0, 0}};
-        int32_t ref[2] = {kNoChild, kNoChild};
-        const int32_t child[2] = {box.leftID, box.rightID};
-        for (int k = 0; k < 2; ++k) {
-            if (child[k] < 0 || (uint64_t)child[k] >= nBox) continue;
-            const RtxBoundingBox& c = s.boxes[child[k]];
-            lo[k][0] = c.minimalPosition.x; lo[k][1] = c.minimalPosition.y; lo[k][2] = c.minimalPosition.z;
-            hi[k][0] = c.maximalPosition.x; hi[k][1] = c.maximalPosition.y; hi[k][2] = c.maximalPosition.z;
-            ref[k] = c.objectID != -1 ? ~posOf[slotOf[child[k]]] : slotOf[child[k]];
-        }
-        float4* n = &f.inner[(size_t)slotOf[b] * 4];
-        n[0] = make_float4(lo[0][0], lo[0][1], lo[0][2], hi[0][0]);
-        n[1] = make_float4(hi[0][1], hi[0][2], lo[1][0], lo[1][1]);
-        n[2] = make_float4(lo[1][2], hi[1][0], hi[1][1], hi[1][2]);
-        n[3] = make_float4(i2f(ref[0]), i2f(ref[1]), 0, 0);
-      }
     });
     f.rootRef = s.boxes[0].objectID != -1 ? ~posOf[slotOf[0]] : slotOf[0];
-    f.seconds[2] = clock.lap("leaf / shade / inner records");
+    f.slotOf.swap(slotOf); f.posOf.swap(posOf);
+    f.numLeaves = (size_t)nLeaf; f.numInner = (size_t)nInner;
+    f.deviceEmit = true;
+    f.seconds[2] = clock.lap("leaf order and ranks");
     return 0;
 }
 
@@ -490,6 +477,76 @@ int upload(T** dst, const void* src, size_t bytes, size_t allocBytes = 0) {
     HIP_TRY(hipMalloc((void**)dst, allocBytes));
     if (allocBytes > bytes) HIP_TRY(hipMemset((char*)*dst + bytes, 0, allocBytes - bytes));
     if (bytes) HIP_TRY(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
+    return 0;
+}
+
+// The caller's objects and boxes on one device, as they are. rtx_create starts the copy on a thread of its own before it
+// flattens, so the 3.8 GB (10 M triangles) cross PCIe while the host builds the tree.
+struct RawUpload {
+    int device = -1;
+    float4 *dObjects = nullptr, *dBoxes = nullptr;
+    std::thread worker;
+    hipError_t err = hipSuccess;
+    bool started = false;
+    static hipError_t copy(int dev, const RtxSceneDesc* sc, float4** dObj, float4** dBox) {
+        hipError_t e = hipSetDevice(dev);
+        const size_t ob = (size_t)sc->numObjects * sizeof(RtxObject), bb = (size_t)sc->numBoxes * sizeof(RtxBoundingBox);
+        if (e == hipSuccess) e = hipMalloc((void**)dObj, std::max<size_t>(ob, 64));
+        if (e == hipSuccess) e = hipMalloc((void**)dBox, std::max<size_t>(bb, 64));
+        if (e == hipSuccess && ob) e = hipMemcpy(*dObj, sc->objects, ob, hipMemcpyHostToDevice);
+        if (e == hipSuccess && bb) e = hipMemcpy(*dBox, sc->boxes, bb, hipMemcpyHostToDevice);
+        return e;
+    }
+    void start(int dev, const RtxSceneDesc* sc) {
+        device = dev; started = true;
+        worker = std::thread([this, dev, sc]() { err = copy(dev, sc, &dObjects, &dBoxes); });
+    }
+    hipError_t wait() { if (worker.joinable()) worker.join(); return err; }
+    void release() {
+        wait();
+        if (device >= 0 && (dObjects || dBoxes)) { hipSetDevice(device); if (dObjects) hipFree(dObjects); if (dBoxes) hipFree(dBoxes); }
+        dObjects = dBoxes = nullptr; started = false;
+    }
+    ~RawUpload() { release(); }
+};
+
+// leaf / shade / reference-topology records of `r`, written by its device from the raw arrays (rtx_kernels.h "device-side flatten")
+int emit_records_on_device(RtxRenderer* r, const RtxSceneDesc* scene, const Flat& flat, RawUpload* raw) {
+    HIP_TRY(hipSetDevice(r->device));
+    float4 *dObj = nullptr, *dBox = nullptr;
+    bool own = false;
+    if (raw && raw->started && raw->device == r->device) {
+        HIP_TRY(raw->wait());
+        dObj = raw->dObjects; dBox = raw->dBoxes;
+    } else {
+        const hipError_t e = RawUpload::copy(r->device, scene, &dObj, &dBox);
+        own = true;
+        if (e != hipSuccess) { if (dObj) hipFree(dObj); if (dBox) hipFree(dBox); return fail(std::string("upload of objects / boxes: ") + hipGetErrorString(e)); }
+    }
+    int2* dPlan = nullptr; int *dSlotOf = nullptr, *dPosOf = nullptr;
+    hipError_t e = hipSuccess;
+    auto ok = [&](hipError_t x) { if (e == hipSuccess) e = x; return e == hipSuccess; };
+    const size_t nl = flat.numLeaves, ni = flat.numInner, nb = (size_t)scene->numBoxes;
+    ok(hipMalloc((void**)&r->dLeaf, std::max<size_t>(nl * 4 * sizeof(float4), 64)));
+    ok(hipMalloc((void**)&r->dShade, std::max<size_t>(nl * 8 * sizeof(float4), 64)));
+    ok(hipMalloc((void**)&r->dInner, std::max<size_t>(ni * 4 * sizeof(float4), 64)));
+    ok(hipMalloc((void**)&dPlan, std::max<size_t>(nl * sizeof(int2), 64)));
+    ok(hipMalloc((void**)&dSlotOf, std::max<size_t>(nb * sizeof(int), 64)));
+    ok(hipMalloc((void**)&dPosOf, std::max<size_t>(nl * sizeof(int), 64)));
+    if (nl) ok(hipMemcpy(dPlan, flat.leafPlan.data(), nl * sizeof(int2), hipMemcpyHostToDevice));
+    if (nb) ok(hipMemcpy(dSlotOf, flat.slotOf.data(), nb * sizeof(int), hipMemcpyHostToDevice));
+    if (nl) ok(hipMemcpy(dPosOf, flat.posOf.data(), nl * sizeof(int), hipMemcpyHostToDevice));
+    if (e == hipSuccess) {
+        if (nl) hipLaunchKernelGGL(k_emit_leaf_records, dim3((uint32_t)((nl + 255) / 256)), dim3(256), 0, 0, dObj, dBox, dPlan, (uint32_t)nl, r->dLeaf, r->dShade);
+        if (nb) hipLaunchKernelGGL(k_emit_inner_records, dim3((uint32_t)((nb + 255) / 256)), dim3(256), 0, 0, dBox, dSlotOf, dPosOf, (uint32_t)nb, r->dInner);
+        ok(hipGetLastError());
+        ok(hipDeviceSynchronize());
+    }
+    void* tmp[] = {dPlan, dSlotOf, dPosOf};
+    for (void* p : tmp) if (p) hipFree(p);
+    if (own) { if (dObj) hipFree(dObj); if (dBox) hipFree(dBox); }
+    else raw->release();                  // consumed
+    if (e != hipSuccess) return fail(std::string("device-side flatten: ") + hipGetErrorString(e));
     return 0;
 }
 
@@ -628,7 +685,7 @@ int check_camera(const RtxCamera* cam) {
 
 } // namespace
 
-static int build_renderer(const RtxSceneDesc* scene, const RtxConfig& cfg, const Flat& flat, bool useBVH, PhaseClock& createClock, RtxRenderer** out);
+static int build_renderer(const RtxSceneDesc* scene, const RtxConfig& cfg, const Flat& flat, bool useBVH, PhaseClock& createClock, RawUpload* raw, RtxRenderer** out);
 
 // ---------------------------------------------------------------------------------
 extern "C" {
@@ -706,11 +763,14 @@ int rtx_create(const RtxSceneDesc* scene, const RtxConfig* cfgIn, RtxRenderer** 
     const bool wantFast = cfg.traversal != RTX_TRAVERSE_EXACT;
     const bool wantQuant = cfg.traversal == RTX_TRAVERSE_WIDE && !getenv("RTX_WIDE_ORDERED");
     PhaseClock createClock;
+    // the raw arrays start for the (first) device now; the records are written there once the leaf order is known
+    RawUpload raw;
+    if (useBVH) raw.start(cfg.numDevices > 1 ? cfg.devices[0] : cfg.device, scene);
     if (flatten(*scene, useBVH, wantFast, wantQuant, 16, flat)) return 1;
     createClock.lap("flatten");
     if (useBVH && flat.maxDepth > 62) return fail("BVH deeper than 62 levels is not supported (the reference's own stack holds 32)");
 
-    if (cfg.numDevices <= 1) return build_renderer(scene, cfg, flat, useBVH, createClock, out);
+    if (cfg.numDevices <= 1) return build_renderer(scene, cfg, flat, useBVH, createClock, &raw, out);
 
     // Device group (single process, several GPUs): member i renders the tiles of rank i of numDevices on devices[i],
     // all from the one flattened scene; member 0 is the handle the caller gets, and delivering a frame gathers the
@@ -720,7 +780,7 @@ int rtx_create(const RtxSceneDesc* scene, const RtxConfig* cfgIn, RtxRenderer** 
         RtxConfig c = cfg;
         c.device = cfg.devices[i]; c.rank = i; c.worldSize = cfg.numDevices; c.numDevices = 0;
         RtxRenderer* m = nullptr;
-        if (build_renderer(scene, c, flat, useBVH, createClock, &m)) { for (RtxRenderer* x : members) rtx_destroy(x); return 1; }
+        if (build_renderer(scene, c, flat, useBVH, createClock, &raw, &m)) { for (RtxRenderer* x : members) rtx_destroy(x); return 1; }
         members.push_back(m);
     }
     RtxRenderer* lead = members[0];
@@ -739,7 +799,7 @@ int rtx_create(const RtxSceneDesc* scene, const RtxConfig* cfgIn, RtxRenderer** 
     return 0;
 }
 
-static int build_renderer(const RtxSceneDesc* scene, const RtxConfig& cfg, const Flat& flat, bool useBVH, PhaseClock& createClock, RtxRenderer** out) {
+static int build_renderer(const RtxSceneDesc* scene, const RtxConfig& cfg, const Flat& flat, bool useBVH, PhaseClock& createClock, RawUpload* raw, RtxRenderer** out) {
     RtxRenderer* r = new RtxRenderer();
     memset(r->ev, 0, sizeof(r->ev));
     r->cfg = cfg; r->device = cfg.device;
@@ -798,11 +858,14 @@ static int build_renderer(const RtxSceneDesc* scene, const RtxConfig& cfg, const
     CREATE_TRY(upload(&r->dTiles, r->localTiles.data(), r->localTiles.size() * sizeof(int2)));
 
     // scene
-    CREATE_TRY(upload(&r->dInner, flat.inner.data(), flat.inner.size() * sizeof(float4)));
+    if (flat.deviceEmit) CREATE_TRY(emit_records_on_device(r, scene, flat, raw));
+    else CREATE_TRY(upload(&r->dInner, flat.inner.data(), flat.inner.size() * sizeof(float4)));
     if (!flat.fast.empty()) CREATE_TRY(upload(&r->dFast, flat.fast.data(), flat.fast.size() * sizeof(rtxbuild::Node4)));
     if (!flat.qnodes.empty()) CREATE_TRY(upload(&r->dQNodes, flat.qnodes.data(), flat.qnodes.size() * sizeof(rtxbuild::NodeQ)));
-    CREATE_TRY(upload(&r->dLeaf, flat.leaf.data(), flat.leaf.size() * sizeof(float4)));
-    CREATE_TRY(upload(&r->dShade, flat.shade.data(), flat.shade.size() * sizeof(float4)));
+    if (!flat.deviceEmit) {
+        CREATE_TRY(upload(&r->dLeaf, flat.leaf.data(), flat.leaf.size() * sizeof(float4)));
+        CREATE_TRY(upload(&r->dShade, flat.shade.data(), flat.shade.size() * sizeof(float4)));
+    }
     CREATE_TRY(upload(&r->dMaterials, scene->materials, scene->numMaterials * sizeof(RtxMaterial)));
     CREATE_TRY(upload(&r->dTexInfo, scene->textureInfo, scene->numTextures * sizeof(RtxTexture)));
     CREATE_TRY(upload(&r->dTexels, scene->textureData, scene->numTexels * sizeof(uint32_t),
@@ -816,8 +879,8 @@ static int build_renderer(const RtxSceneDesc* scene, const RtxConfig& cfg, const
     r->sc.qnodes = r->dQNodes;
     r->sc.cullSlack = (flat.sliverFraction > 1e-3 || cfg.traversal == RTX_TRAVERSE_WIDE) ? INFINITY : RTX_CULL_SLACK_DEFAULT;
     if (const char* e = getenv("RTX_CULL_SLACK")) if (cfg.traversal == RTX_TRAVERSE_CULLED) r->sc.cullSlack = (float)atof(e);      // experiments
-    r->sc.numLeaves = (int)(flat.leaf.size() / 4);
-    r->sc.numInner = (int)(flat.inner.size() / 4);
+    r->sc.numLeaves = (int)flat.numLeaves;
+    r->sc.numInner = (int)flat.numInner;
     r->sc.numMaterials = (int)scene->numMaterials;
     r->sc.numTextures = (int)scene->numTextures;
     // textureInfo[1] is hard-wired as the sky (src/ThreadedShader.cpp:162); with a

@@ -656,6 +656,76 @@ __global__ void k_stage_directions(const float4* __restrict__ in, float4* __rest
     out[q] = make_float4(d.x, d.y, d.z, 0.0f);
 }
 
+// ---- device-side flatten -------------------------------------------------------------
+// rtx_create uploads the caller's objects (256 B) and boxes (64 B) as they are and builds the traversal records here:
+// the host only decides WHERE every leaf goes (the own tree's leaf order) and its tie-break rank. Same arithmetic as
+// the host would do — e1 = B - A, e2 = C - A are the reference's own first two subtractions (src/ThreadedShader.cpp:298-299).
+// Object words: [0] = (type radius - -) [1] = position [2..4] = normals [5..7] = vertices [11].x = materialID.
+// Box words: [0] = (objectID parentID leftID rightID) [1] = min [2] = max.
+__global__ void k_emit_leaf_records(const float4* __restrict__ objects, const float4* __restrict__ boxes, const int2* __restrict__ plan,
+                                    uint32_t n, float4* __restrict__ leaf, float4* __restrict__ shade) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const int2 pl = plan[p];                                     // (box index, tie-break rank)
+    const float4* B = boxes + (size_t)pl.x * 4;
+    const float4 b0 = B[0], bmin = B[1], bmax = B[2];
+    const int objectID = __float_as_int(b0.x);
+    const float4* O = objects + (size_t)objectID * 16;
+    const float4 o0 = O[0], pos = O[1], n0 = O[2], n1 = O[3], n2 = O[4], vA = O[5], vB = O[6], vC = O[7];
+    const int type = __float_as_int(o0.x);
+    const int materialID = __float_as_int(O[11].x);
+    float4 q0, q1, q3; float e2z;
+    if (type == 4 /* RTX_TRIANGLE */) {
+        const float e1x = vB.x - vA.x, e1y = vB.y - vA.y, e1z = vB.z - vA.z;
+        const float e2x = vC.x - vA.x, e2y = vC.y - vA.y; e2z = vC.z - vA.z;
+        q0 = make_float4(vA.x, vA.y, vA.z, e1x);
+        q1 = make_float4(e1y, e1z, e2x, e2y);
+        q3 = make_float4(vB.x, vB.y, vC.x, vC.y);
+    } else {
+        q0 = make_float4(pos.x, pos.y, pos.z, o0.y);
+        q1 = make_float4(0, 0, 0, 0); q3 = make_float4(0, 0, 0, 0); e2z = 0.0f;
+    }
+    // every type but TRIANGLE is intersected as a sphere (src/ThreadedShader.cpp:364-368)
+    const int tag = (int)(((uint32_t)pl.y << 3) | (type == 4 ? 4u : 0u));
+    float4* L = leaf + (size_t)p * 4;
+    L[0] = q0; L[1] = q1;
+    L[2] = make_float4(e2z, __int_as_float(tag), bmin.x, bmin.y);
+    L[3] = make_float4(bmin.z, bmax.x, bmax.y, bmax.z);
+    float4* S = shade + (size_t)p * 8;
+    S[0] = q0; S[1] = q1;
+    S[2] = make_float4(e2z, __int_as_float(objectID), __int_as_float(pl.x), __int_as_float(type));
+    S[3] = q3;
+    S[4] = make_float4(n0.x, n0.y, n0.z, n1.x);
+    S[5] = make_float4(n1.y, n1.z, n2.x, n2.y);
+    S[6] = make_float4(n2.z, __int_as_float(materialID), 0, 0);
+    S[7] = make_float4(0, 0, 0, 0);
+}
+
+// The reference's own topology as 64-byte records: both children's boxes + both child refs (>= 0 inner record,
+// < 0 ~leaf position, RTX_NO_CHILD for an absent child).
+__global__ void k_emit_inner_records(const float4* __restrict__ boxes, const int* __restrict__ slotOf, const int* __restrict__ posOf,
+                                     uint32_t nBox, float4* __restrict__ inner) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nBox) return;
+    const float4 b0 = boxes[(size_t)b * 4];
+    if (__float_as_int(b0.x) != -1) return;                      // a leaf box
+    const int child[2] = {__float_as_int(b0.z), __float_as_int(b0.w)};
+    float4 lo[2] = {make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0)}, hi[2] = {make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0)};
+    int ref[2] = {RTX_NO_CHILD, RTX_NO_CHILD};
+    for (int k = 0; k < 2; ++k) {
+        if (child[k] < 0 || (uint32_t)child[k] >= nBox) continue;
+        const float4* C = boxes + (size_t)child[k] * 4;
+        const float4 c0 = C[0];
+        lo[k] = C[1]; hi[k] = C[2];
+        ref[k] = __float_as_int(c0.x) != -1 ? ~posOf[slotOf[child[k]]] : slotOf[child[k]];
+    }
+    float4* N = inner + (size_t)slotOf[b] * 4;
+    N[0] = make_float4(lo[0].x, lo[0].y, lo[0].z, hi[0].x);
+    N[1] = make_float4(hi[0].y, hi[0].z, lo[1].x, lo[1].y);
+    N[2] = make_float4(lo[1].z, hi[1].x, hi[1].y, hi[1].z);
+    N[3] = make_float4(__int_as_float(ref[0]), __int_as_float(ref[1]), 0, 0);
+}
+
 // ---- present ---------------------------------------------------------------------
 // The running mean as the 8-bit RGBA image a display path consumes (the reference uploads its float pixels into a
 // GL_RGBA texture, src/WindowManager.cpp:18,165, i.e. GL clamps to [0,1] and rounds to 8 bits; here that conversion
