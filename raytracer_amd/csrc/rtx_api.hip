@@ -143,8 +143,8 @@ namespace {
 
 struct Flat {
     std::vector<float4> inner, leaf, shade;
-    std::vector<rtxbuild::Node4> fast;  // own 4-wide SAH tree over the same leaves (empty: not built)
-    std::vector<rtxbuild::NodeQ> qnodes; // the same tree with byte boxes (RTX_TRAVERSE_WIDE); `fast` is dropped when this is built
+    rtxbuild::Raw<rtxbuild::Node4> fast;  // own 4-wide SAH tree over the same leaves (empty: not built)
+    rtxbuild::Raw<rtxbuild::NodeQ> qnodes; // the same tree with byte boxes (RTX_TRAVERSE_WIDE); `fast` is dropped when this is built
     int rootRef = 0, fastRoot = 0;
     int maxDepth = 0, fastDepth = 0;
     bool nested = true;                 // every box contains its children (precondition of the own tree)
@@ -403,7 +403,7 @@ int flatten(const RtxSceneDesc& s, bool useBVH, bool wantFast, bool wantQuant, i
     std::vector<uint32_t> order((size_t)nLeaf);
     for (int32_t k = 0; k < nLeaf; ++k) order[k] = (uint32_t)k;
     if (wantFast && f.nested && nLeaf >= 2) {
-        std::vector<rtxbuild::Box> prim((size_t)nLeaf);
+        rtxbuild::Raw<rtxbuild::Box> prim((size_t)nLeaf);
         parallel_for((uint64_t)nLeaf, nthreads, [&](uint64_t k0, uint64_t k1) {
             for (uint64_t k = k0; k < k1; ++k) {
                 const RtxBoundingBox& b = s.boxes[leafBox[k]];
@@ -411,7 +411,7 @@ int flatten(const RtxSceneDesc& s, bool useBVH, bool wantFast, bool wantQuant, i
                 prim[k].hi[0] = b.maximalPosition.x; prim[k].hi[1] = b.maximalPosition.y; prim[k].hi[2] = b.maximalPosition.z;
             }
         });
-        std::vector<rtxbuild::Node> bin((size_t)nLeaf - 1);
+        rtxbuild::Raw<rtxbuild::Node> bin((size_t)nLeaf - 1);
         int binDepth = 0;
         const int32_t binRoot = rtxbuild::build_sah(prim.data(), (uint32_t)nLeaf, order.data(), bin.data(), nthreads, binDepth);
         f.seconds[1] += clock.lap("binned-SAH build");
@@ -440,10 +440,10 @@ int flatten(const RtxSceneDesc& s, bool useBVH, bool wantFast, bool wantQuant, i
             std::vector<uint32_t> order2((size_t)nLeaf);
             parallel_for((uint64_t)nLeaf, nthreads, [&](uint64_t p0, uint64_t p1) { for (uint64_t p = p0; p < p1; ++p) order2[p] = order[newToOld[p]]; });
             order.swap(order2);
-            std::vector<rtxbuild::Node4>().swap(f.fast);
+            rtxbuild::Raw<rtxbuild::Node4>().swap(f.fast);
         } else {
             f.qnodes.clear();          // a box extent that is not finite: keep the reference topology
-            std::vector<rtxbuild::Node4>().swap(f.fast);
+            rtxbuild::Raw<rtxbuild::Node4>().swap(f.fast);
             for (int32_t k = 0; k < nLeaf; ++k) order[k] = (uint32_t)k;
         }
         f.seconds[1] += clock.lap("quantise nodes");

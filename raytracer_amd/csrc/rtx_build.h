@@ -14,16 +14,33 @@
 // once and sibling subtrees are built on separate threads.
 #pragma once
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <memory>
 #include <thread>
+#include <utility>
 #include <vector>
 #if defined(__SSE__)
 #include <xmmintrin.h>
 #endif
 
 namespace rtxbuild {
+
+// std::vector whose resize / sized constructor leaves trivially constructible elements untouched: the big arrays of
+// the build are written in full by the threads that fill them, and a value-initialising vector would first walk
+// (and page in) every one of them on the calling thread — a quarter of the build time at 10 M primitives.
+template <class T>
+struct NoInitAlloc : std::allocator<T> {
+    template <class U> struct rebind { typedef NoInitAlloc<U> other; };
+    NoInitAlloc() = default;
+    template <class U> NoInitAlloc(const NoInitAlloc<U>&) {}
+    template <class U> void construct(U*) {}                                             // value-init request: do nothing
+    template <class U, class A0, class... A> void construct(U* p, A0&& a0, A&&... a) { ::new ((void*)p) U(std::forward<A0>(a0), std::forward<A>(a)...); }
+};
+template <class T> using Raw = std::vector<T, NoInitAlloc<T>>;
 
 struct Box { float lo[3], hi[3]; };
 
@@ -290,19 +307,28 @@ struct SahBuilder {
 // order[] in: any permutation of 0..n-1; out: leaf order of the new tree.
 // Returns the root ref; nodes must hold n-1 records.
 inline int32_t build_sah(const Box* prim, uint32_t n, uint32_t* order, Node* nodes, int nthreads, int& maxDepth) {
-    std::vector<Item> items(n), scratch(n);
-    // the root's centroid bounds: the only pass of this kind
+    Raw<Item> items(n), scratch(n);
+    // the root's centroid bounds: the only pass of this kind (on all threads: it is also the first touch of `items`)
     Box cb = empty_box();
-    for (uint32_t i = 0; i < n; ++i) {
-        const Box& pb = prim[order[i]];
-        for (int a = 0; a < 3; ++a) { items[i].lo[a] = pb.lo[a]; items[i].hi[a] = pb.hi[a]; }
-        items[i].id = order[i]; items[i].pad = 0;
-        SahBuilder::grow_centroid(cb, items[i]);
+    {
+        const int T = nthreads < 1 ? 1 : (n < 65536 ? 1 : nthreads);
+        std::vector<Box> part((size_t)T, empty_box());
+        SahBuilder::parallel_chunks(0, n, T, [&](int t, uint32_t b, uint32_t e) {
+            Box local = empty_box();
+            for (uint32_t i = b; i < e; ++i) {
+                const Box& pb = prim[order[i]];
+                for (int a = 0; a < 3; ++a) { items[i].lo[a] = pb.lo[a]; items[i].hi[a] = pb.hi[a]; }
+                items[i].id = order[i]; items[i].pad = 0;
+                SahBuilder::grow_centroid(local, items[i]);
+            }
+            part[(size_t)t] = local;
+        });
+        for (const Box& pbx : part) grow(cb, pbx);
     }
     SahBuilder b{items.data(), nodes, scratch.data()};
     Box root; int depth = 0;
     const int32_t ref = b.build(0, n, 0, 0, cb, nthreads < 1 ? 1 : nthreads, root, depth);
-    for (uint32_t i = 0; i < n; ++i) order[i] = items[i].id;
+    SahBuilder::parallel_chunks(0, n, nthreads < 1 ? 1 : (n < 65536 ? 1 : nthreads), [&](int, uint32_t b, uint32_t e) { for (uint32_t i = b; i < e; ++i) order[i] = items[i].id; });
     maxDepth = depth;
     return ref;
 }
@@ -323,14 +349,14 @@ inline int32_t build_sah(const Box* prim, uint32_t n, uint32_t* order, Node* nod
 //     split(n, j) = min over k of T[left][k] + T[right][j - k];   T[leaf][.] = 0
 // Greedy "expand the largest child" leaves 3.0 children per node on the synthetic meshes; this gives
 // fuller nodes and fewer, smaller ones.
-struct Node4 {          // 128-byte record: lo.x[4] hi.x[4] lo.y[4] hi.y[4] lo.z[4] hi.z[4] ref[4] pad[4]
+struct Node4 {          // 128-byte record: lo.x[4] hi.x[4] lo.y[4] hi.y[4] lo.z[4] hi.z[4] ref[4] (nodes, leaves of the subtree, as ints) pad[2]
     float q[32];
 };
 
 struct Collapser {
     const Node* bvh2;
-    std::vector<Node4>& out;
-    std::vector<float> T;      // 4 per binary node: T[4 * n + j - 1]
+    Raw<Node4>& out;
+    Raw<float> T;              // 4 per binary node: T[4 * n + j - 1]; every entry is written by solve()
     int maxDepth = 0;
 
     struct Child { Box box; int32_t ref; };
@@ -384,22 +410,8 @@ struct Collapser {
         collect(c[1], j - k, slots, n);
     }
 
-    // emits the wide node for binary node `ref2` (>= 0) and returns its index
-    int32_t emit(int32_t ref2, int depth) {
-        maxDepth = std::max(maxDepth, depth);
-        Child c2[2]; children_of(bvh2[ref2], c2);
-        int k; split(c2, 4, k);
-        Child c[4]; int n = 0;
-        collect(c2[0], k, c, n);
-        collect(c2[1], 4 - k, c, n);
-        const int32_t idx = (int32_t)out.size();
-        out.emplace_back();
-        int32_t refs[4];
-        for (int i = 0; i < 4; ++i) {
-            if (i < n) refs[i] = c[i].ref >= 0 ? emit(c[i].ref, depth + 1) : c[i].ref;
-            else refs[i] = (int32_t)0x80000000;                       // RTX_NO_CHILD
-        }
-        float* q = out[idx].q;
+    static void write_node4(Node4& node, const Child* c, int n, const int32_t* refs, int32_t subNodes, int32_t subLeaves) {
+        float* q = node.q;
         for (int i = 0; i < 4; ++i) {
             const bool used = i < n;
             for (int a = 0; a < 3; ++a) {
@@ -407,23 +419,139 @@ struct Collapser {
                 q[8 * a + 4 + i] = used ? c[i].box.hi[a] : NAN;       // every comparison with its NaN distances is false
             }
             q[24 + i] = i2f(refs[i]);
-            q[28 + i] = 0.0f;
         }
+        q[28] = i2f(subNodes); q[29] = i2f(subLeaves); q[30] = 0.0f; q[31] = 0.0f;     // sizes of the subtree (quantize4 numbers with them)
+    }
+
+    // emits the wide node for binary node `ref2` (>= 0) into dst (pre-order: a node before its subtrees) and returns its index
+    int32_t emit(int32_t ref2, int depth, Raw<Node4>& dst, int& deepest) const {
+        deepest = std::max(deepest, depth);
+        Child c2[2]; children_of(bvh2[ref2], c2);
+        int k; split(c2, 4, k);
+        Child c[4]; int n = 0;
+        collect(c2[0], k, c, n);
+        collect(c2[1], 4 - k, c, n);
+        const int32_t idx = (int32_t)dst.size();
+        dst.emplace_back();
+        int32_t refs[4], nodes = 1, leaves = 0;
+        for (int i = 0; i < 4; ++i) {
+            if (i >= n) { refs[i] = (int32_t)0x80000000; continue; }  // RTX_NO_CHILD
+            if (c[i].ref < 0) { refs[i] = c[i].ref; leaves++; continue; }
+            refs[i] = emit(c[i].ref, depth + 1, dst, deepest);
+            nodes += f2i(dst[(size_t)refs[i]].q[28]); leaves += f2i(dst[(size_t)refs[i]].q[29]);
+        }
+        write_node4(dst[(size_t)idx], c, n, refs, nodes, leaves);
         return idx;
+    }
+
+    // The same tree, emitted on several threads: the top of the tree is emitted here, and every subtree of at most
+    // `grain` binary nodes it meets becomes a task; the tasks are emitted into vectors of their own (indices relative
+    // to the subtree) and appended behind the top in the order they were met, so the layout does not depend on timing.
+    // Binary nodes are in pre-order (build_sah): the subtree of node x is the index range [x, end).
+    struct Task { int32_t ref2, end; int depth; int32_t parent; int slot; Raw<Node4> nodes; int deepest = 0; };
+    int32_t emit_top(int32_t ref2, int32_t end, int depth, size_t grain, std::vector<Task>& tasks) {
+        maxDepth = std::max(maxDepth, depth);
+        Child c2[2]; children_of(bvh2[ref2], c2);
+        int k; split(c2, 4, k);
+        Child c[4]; int32_t ends[4]; int n = 0;
+        // index ranges of the two binary children, then of whatever `collect` dissolves them into
+        collect_ranges(c2[0], c2[1].ref >= 0 ? c2[1].ref : end, k, c, ends, n);
+        collect_ranges(c2[1], end, 4 - k, c, ends, n);
+        const int32_t idx = (int32_t)out.size();
+        out.emplace_back();
+        int32_t refs[4];
+        for (int i = 0; i < 4; ++i) {
+            if (i >= n) { refs[i] = (int32_t)0x80000000; continue; }
+            if (c[i].ref < 0) { refs[i] = c[i].ref; continue; }
+            if ((size_t)(ends[i] - c[i].ref) <= grain) {
+                refs[i] = 0;                                           // patched once the task's position is known
+                tasks.emplace_back();
+                Task& t = tasks.back();
+                t.ref2 = c[i].ref; t.end = ends[i]; t.depth = depth + 1; t.parent = idx; t.slot = i;
+            } else {
+                refs[i] = emit_top(c[i].ref, ends[i], depth + 1, grain, tasks);
+            }
+        }
+        write_node4(out[(size_t)idx], c, n, refs, 0, 0);              // sizes: collapse4 fills them in when the tasks are done
+        return idx;
+    }
+    void collect_ranges(const Child& me, int32_t meEnd, int j, Child* slots, int32_t* ends, int& n) const {
+        if (me.ref < 0 || j == 1 || !(t(me.ref, j) < t(me.ref, 1))) { ends[n] = meEnd; slots[n++] = me; return; }
+        Child c[2]; children_of(bvh2[me.ref], c);
+        int k; split(c, j, k);
+        collect_ranges(c[0], c[1].ref >= 0 ? c[1].ref : meEnd, k, slots, ends, n);
+        collect_ranges(c[1], meEnd, j - k, slots, ends, n);
     }
 };
 
 // Folds the binary tree of `numNodes` inner nodes rooted at node `root2` into 4-wide nodes (root = index 0).
-inline void collapse4(const Node* bvh2, size_t numNodes, int32_t root2, std::vector<Node4>& out, int& maxDepth, int nthreads = 1) {
+inline void collapse4(const Node* bvh2, size_t numNodes, int32_t root2, Raw<Node4>& out, int& maxDepth, int nthreads = 1) {
     Collapser c{bvh2, out};
-    c.T.assign(4 * numNodes, 0.0f);
-    c.solve((size_t)root2, numNodes, nthreads < 1 ? 1 : nthreads);
-    c.emit(root2, 0);
+    c.T.resize(4 * numNodes);
+    if (nthreads < 1) nthreads = 1;
+    c.solve((size_t)root2, numNodes, nthreads);
+    if (nthreads == 1 || numNodes < 65536) {
+        c.emit(root2, 0, out, c.maxDepth);
+        maxDepth = c.maxDepth;
+        return;
+    }
+    std::vector<Collapser::Task> tasks;
+    const size_t grain = std::max<size_t>(4096, numNodes / ((size_t)nthreads * 8));
+    c.emit_top(root2, (int32_t)numNodes, 0, grain, tasks);
+    const size_t top = out.size();
+    {
+        std::atomic<size_t> next{0};
+        std::vector<std::thread> pool;
+        auto worker = [&]() {
+            for (size_t i = next++; i < tasks.size(); i = next++) {
+                Collapser::Task& t = tasks[i];
+                t.nodes.reserve((size_t)(t.end - t.ref2) / 2 + 4);
+                c.emit(t.ref2, t.depth, t.nodes, t.deepest);
+            }
+        };
+        for (int k = 1; k < nthreads; ++k) pool.emplace_back(worker);
+        worker();
+        for (auto& th : pool) th.join();
+    }
+    std::vector<size_t> base(tasks.size() + 1, top);
+    for (size_t i = 0; i < tasks.size(); ++i) base[i + 1] = base[i] + tasks[i].nodes.size();
+    out.resize(base.back());
+    {
+        std::atomic<size_t> next{0};
+        std::vector<std::thread> pool;
+        auto worker = [&]() {
+            for (size_t i = next++; i < tasks.size(); i = next++) {
+                const Collapser::Task& t = tasks[i];
+                const int32_t off = (int32_t)base[i];
+                Node4* dst = out.data() + base[i];
+                for (size_t k = 0; k < t.nodes.size(); ++k) {
+                    dst[k] = t.nodes[k];
+                    for (int j = 0; j < 4; ++j) { const int32_t r = f2i(dst[k].q[24 + j]); if (r >= 0) dst[k].q[24 + j] = i2f(r + off); }
+                }
+            }
+        };
+        for (int k = 1; k < nthreads; ++k) pool.emplace_back(worker);
+        worker();
+        for (auto& th : pool) th.join();
+    }
+    for (size_t i = 0; i < tasks.size(); ++i) {
+        out[(size_t)tasks[i].parent].q[24 + tasks[i].slot] = i2f((int32_t)base[i]);
+        c.maxDepth = std::max(c.maxDepth, tasks[i].deepest);
+    }
+    for (size_t i = top; i-- > 0;) {                                  // subtree sizes of the top nodes (children have higher indices)
+        int32_t nodes = 1, leaves = 0;
+        for (int j = 0; j < 4; ++j) {
+            const int32_t r = f2i(out[i].q[24 + j]);
+            if (r >= 0) { nodes += f2i(out[(size_t)r].q[28]); leaves += f2i(out[(size_t)r].q[29]); }
+            else if (r != (int32_t)0x80000000) leaves++;
+        }
+        out[i].q[28] = i2f(nodes); out[i].q[29] = i2f(leaves);
+    }
     maxDepth = c.maxDepth;
 }
 
 // A wide node holding a single leaf (scenes with one primitive) or nothing at all.
-inline void single_leaf_node4(const Box* leafBox, std::vector<Node4>& out) {
+inline void single_leaf_node4(const Box* leafBox, Raw<Node4>& out) {
     out.emplace_back();
     float* q = out.back().q;
     for (int k = 0; k < 4; ++k) {
@@ -432,6 +560,7 @@ inline void single_leaf_node4(const Box* leafBox, std::vector<Node4>& out) {
         q[24 + k] = i2f(used ? ~0 : (int32_t)0x80000000);
         q[28 + k] = 0.0f;
     }
+    q[28] = i2f(1); q[29] = i2f(leafBox ? 1 : 0);
 }
 
 // ---- quantised 4-wide nodes ----------------------------------------------------------
@@ -459,39 +588,75 @@ struct NodeQ {          // 64-byte slot, 48 bytes used
 // Converts the Node4 tree (root = node 0) into NodeQ records (root = node 0 again) and returns, for every new leaf
 // position, the position the leaf had in the order the Node4 tree refers to. false: a box extent is not finite
 // (the caller keeps the reference topology then).
-inline bool quantize4(const std::vector<Node4>& in, std::vector<NodeQ>& out, std::vector<uint32_t>& leafNewToOld, int nthreads) {
+inline bool quantize4(const Raw<Node4>& in, Raw<NodeQ>& out, std::vector<uint32_t>& leafNewToOld, int nthreads, double* phaseSeconds = nullptr) {
+    auto tick = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double tStart = tick();
     const int32_t kNone = (int32_t)0x80000000;
     const size_t n = in.size();
     struct Plan { int32_t newIdx, baseInner, baseLeaf; uint8_t slot[4], ni, nl; };
-    std::vector<Plan> plan(n);
+    Raw<Plan> plan(n);
     leafNewToOld.clear();
-    // numbering: a node's inner children take consecutive indices, handed out when the node is visited; the walk
-    // then descends into the first child, so a subtree's blocks stay near each other in memory
-    {
-        std::vector<int32_t> st; st.push_back(0);
-        plan[0].newIdx = 0;
-        int32_t nextNode = 1;
-        while (!st.empty()) {
-            const int32_t i = st.back(); st.pop_back();
-            Plan& p = plan[(size_t)i];
-            const float* q = in[(size_t)i].q;
-            p.ni = p.nl = 0;
-            for (int k = 0; k < 4; ++k) { const int32_t r = f2i(q[24 + k]); if (r >= 0) p.slot[p.ni++] = (uint8_t)k; }
-            for (int k = 0; k < 4; ++k) { const int32_t r = f2i(q[24 + k]); if (r < 0 && r != kNone) p.slot[p.ni + p.nl++] = (uint8_t)k; }
-            p.baseInner = nextNode;
-            p.baseLeaf = (int32_t)leafNewToOld.size() - (int32_t)p.ni;
-            for (int j = 0; j < p.ni; ++j) plan[(size_t)f2i(q[24 + p.slot[j]])].newIdx = nextNode++;
-            for (int j = 0; j < p.nl; ++j) leafNewToOld.push_back((uint32_t)~f2i(q[24 + p.slot[p.ni + j]]));
-            for (int j = p.ni; j-- > 0;) st.push_back(f2i(q[24 + p.slot[j]]));
+    // Numbering: a node's inner children take consecutive indices ("block"), handed out when the node is visited, and
+    // the walk then descends into the first child — so the descendants of child k follow the block and the
+    // descendants of the children before it, and likewise for leaves. With the subtree sizes the fold left in every
+    // node that is arithmetic: the top of the tree is numbered here, subtrees of at most `grain` nodes on all threads.
+    if (n && (f2i(in[0].q[28]) != (int32_t)n || f2i(in[0].q[29]) < 0)) return false;       // sizes missing
+    leafNewToOld.assign(n ? (size_t)f2i(in[0].q[29]) : 0, 0u);
+    const double tSizes = tick();
+    struct Job { int32_t node, newIdx, descBase, leafBase; };
+    auto number_node = [&](const Job& j, Job* kids) -> int {          // fills plan[j.node], returns the inner children as jobs
+        Plan& p = plan[(size_t)j.node];
+        const float* q = in[(size_t)j.node].q;
+        p.newIdx = j.newIdx;
+        p.ni = p.nl = 0;
+        for (int k = 0; k < 4; ++k) { const int32_t r = f2i(q[24 + k]); if (r >= 0) p.slot[p.ni++] = (uint8_t)k; }
+        for (int k = 0; k < 4; ++k) { const int32_t r = f2i(q[24 + k]); if (r < 0 && r != kNone) p.slot[p.ni + p.nl++] = (uint8_t)k; }
+        p.baseInner = j.descBase;
+        p.baseLeaf = j.leafBase - (int32_t)p.ni;
+        for (int m = 0; m < p.nl; ++m) leafNewToOld[(size_t)(j.leafBase + m)] = (uint32_t)~f2i(q[24 + p.slot[p.ni + m]]);
+        int32_t nextDesc = j.descBase + (int32_t)p.ni, nextLeaf = j.leafBase + (int32_t)p.nl;
+        for (int m = 0; m < p.ni; ++m) {
+            const int32_t c = f2i(q[24 + p.slot[m]]);
+            kids[m] = Job{c, j.descBase + m, nextDesc, nextLeaf};
+            nextDesc += f2i(in[(size_t)c].q[28]) - 1; nextLeaf += f2i(in[(size_t)c].q[29]);
         }
+        return p.ni;
+    };
+    auto number_subtree = [&](const Job& root) {
+        std::vector<Job> st{root};
+        Job kids[4];
+        while (!st.empty()) {
+            const Job j = st.back(); st.pop_back();
+            const int k = number_node(j, kids);
+            for (int m = k; m-- > 0;) st.push_back(kids[m]);
+        }
+    };
+    if (n) {
+        const int32_t grain = (int32_t)std::max<size_t>(1024, n / ((size_t)std::max(1, nthreads) * 8));
+        std::vector<Job> top{Job{0, 0, 1, 0}}, jobs;
+        Job kids[4];
+        while (!top.empty()) {
+            const Job j = top.back(); top.pop_back();
+            if (nthreads > 1 && f2i(in[(size_t)j.node].q[28]) <= grain) { jobs.push_back(j); continue; }
+            const int k = number_node(j, kids);
+            for (int m = k; m-- > 0;) top.push_back(kids[m]);
+        }
+        std::atomic<size_t> next{0};
+        std::vector<std::thread> pool;
+        auto worker = [&]() { for (size_t i = next++; i < jobs.size(); i = next++) number_subtree(jobs[i]); };
+        for (int t = 1; t < nthreads && t < (int)jobs.size(); ++t) pool.emplace_back(worker);
+        worker();
+        for (auto& th : pool) th.join();
     }
-    out.assign(n, NodeQ{});
+    const double tNumbered = tick();
+    out.resize(n);                                                  // every word is written below
     std::vector<uint8_t> bad((size_t)std::max(1, nthreads), 0);
     auto work = [&](int t, size_t b, size_t e) {
         for (size_t i = b; i < e; ++i) {
             const Plan& p = plan[i];
             const float* q = in[i].q;
             NodeQ& o = out[(size_t)p.newIdx];
+            o.w[12] = o.w[13] = o.w[14] = o.w[15] = 0;
             const int nc = p.ni + p.nl;
             uint32_t meta = 0;
             for (int a = 0; a < 3; ++a) {
@@ -539,6 +704,7 @@ inline bool quantize4(const std::vector<Node4>& in, std::vector<NodeQ>& out, std
     } else {
         work(0, 0, n);
     }
+    if (phaseSeconds) { phaseSeconds[0] = tSizes - tStart; phaseSeconds[1] = tNumbered - tSizes; phaseSeconds[2] = tick() - tNumbered; }
     for (uint8_t b : bad) if (b) return false;
     return true;
 }

@@ -13,7 +13,7 @@ static int fails = 0;
 #define CHECK(c) do { if (!(c)) { if (fails++ < 10) printf("FAIL line %d: %s\n", __LINE__, #c); } } while (0)
 
 struct Walker {
-    const std::vector<Node4>& nodes; const std::vector<Box>& prim; const std::vector<uint32_t>& order;
+    const Raw<Node4>& nodes; const std::vector<Box>& prim; const std::vector<uint32_t>& order;
     std::vector<int> seen; int maxDepth = 0; size_t visited = 0;
     Box walk(int32_t ref, int depth) {
         if (ref < 0) {
@@ -43,8 +43,8 @@ struct Walker {
 // inner children neighbours in the node array and its leaf children neighbours in the new leaf order; every DECODED
 // box — fma(byte, 2^e, origin), the operation the kernel performs — contains the float box of the child it stands for
 // (the property the traversal's exactness argument rests on), and is at most one grid step larger on each side.
-static void check_quantised(const std::vector<Node4>& wide, uint32_t n, int threads, float huge = 0.0f) {
-    std::vector<NodeQ> q; std::vector<uint32_t> newToOld;
+static void check_quantised(const Raw<Node4>& wide, uint32_t n, int threads, float huge = 0.0f) {
+    Raw<NodeQ> q; std::vector<uint32_t> newToOld;
     const bool ok = quantize4(wide, q, newToOld, threads);
     CHECK(ok);
     if (!ok) return;
@@ -111,7 +111,7 @@ static void run(uint32_t n, unsigned seed, int threads, bool degenerate) {
     CHECK(root == 0);
     std::vector<uint32_t> sorted = order; std::sort(sorted.begin(), sorted.end());
     for (uint32_t i = 0; i < n; ++i) CHECK(sorted[i] == i);                       // still a permutation
-    std::vector<Node4> wide; int depth4 = 0;
+    Raw<Node4> wide; int depth4 = 0;
     collapse4(bin.data(), bin.size(), root, wide, depth4, threads);
     CHECK(wide.size() <= bin.size());
     Walker w{wide, prim, order, std::vector<int>(n, 0)};
@@ -128,11 +128,11 @@ static void run(uint32_t n, unsigned seed, int threads, bool degenerate) {
 int main() {
     run(2, 1, 1, false); run(3, 2, 1, false); run(5, 3, 2, false); run(1000, 4, 4, false); run(200000, 5, 8, false);
     run(4097, 6, 4, true);
-    std::vector<Node4> one; Box b; for (int a = 0; a < 3; ++a) { b.lo[a] = 1; b.hi[a] = 2; }
+    Raw<Node4> one; Box b; for (int a = 0; a < 3; ++a) { b.lo[a] = 1; b.hi[a] = 2; }
     single_leaf_node4(&b, one);
     CHECK(one.size() == 1 && f2i(one[0].q[24]) == ~0 && f2i(one[0].q[25]) == (int32_t)0x80000000 && std::isnan(one[0].q[1]));
     check_quantised(one, 1, 1);
-    std::vector<Node4> none; single_leaf_node4(nullptr, none);
+    Raw<Node4> none; single_leaf_node4(nullptr, none);
     check_quantised(none, 0, 1);
     {   // extreme coordinates: a huge box next to a tiny one far from the origin, and an infinite extent (must be refused)
         std::vector<Box> prim(3);
@@ -140,13 +140,13 @@ int main() {
         for (int i = 0; i < 3; ++i) for (int a = 0; a < 3; ++a) { prim[i].lo[a] = v[i][0]; prim[i].hi[a] = v[i][1]; }
         std::vector<uint32_t> order{0, 1, 2}; std::vector<Node> bin(2); int d = 0;
         const int32_t root = build_sah(prim.data(), 3, order.data(), bin.data(), 1, d);
-        std::vector<Node4> wide; int d4 = 0; collapse4(bin.data(), bin.size(), root, wide, d4, 1);
+        Raw<Node4> wide; int d4 = 0; collapse4(bin.data(), bin.size(), root, wide, d4, 1);
         check_quantised(wide, 3, 1, 1e33f);
         prim[0].hi[1] = INFINITY;
         order = {0, 1, 2};
         const int32_t root2 = build_sah(prim.data(), 3, order.data(), bin.data(), 1, d);
         wide.clear(); collapse4(bin.data(), bin.size(), root2, wide, d4, 1);
-        std::vector<NodeQ> q; std::vector<uint32_t> n2o;
+        Raw<NodeQ> q; std::vector<uint32_t> n2o;
         CHECK(!quantize4(wide, q, n2o, 1));
     }
     if (fails) { printf("%d check(s) failed\n", fails); return 1; }
