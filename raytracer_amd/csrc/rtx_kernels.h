@@ -175,8 +175,16 @@ __device__ __forceinline__ void primary_ray(const DevFrame& fr, int x, int y, ui
 // 5 waves per SIMD: ray generation (double-precision jitter and NDC arithmetic) would otherwise claim 115
 // VGPRs for the whole kernel and leave 4 waves; capped at 96 it spills 13 dwords outside the traversal loop
 // and the launch runs 9 % faster.
+#ifndef RTX_PRIMARY_WAVES
+#define RTX_PRIMARY_WAVES 5
+#endif
+#if RTX_PRIMARY_WAVES > 0
+#define RTX_PRIMARY_ATTR __attribute__((amdgpu_waves_per_eu(RTX_PRIMARY_WAVES, RTX_PRIMARY_WAVES)))
+#else
+#define RTX_PRIMARY_ATTR
+#endif
 template <int MODE, bool COUNT>
-__global__ __launch_bounds__(RTX_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_primary(DevScene sc, DevBatch bt, const int2* __restrict__ tiles,
+__global__ __launch_bounds__(RTX_BLOCK) RTX_PRIMARY_ATTR void k_primary(DevScene sc, DevBatch bt, const int2* __restrict__ tiles,
                                                        float4* __restrict__ rqO, float4* __restrict__ rqD,
                                                        float* __restrict__ hitT, int* __restrict__ hitLeaf,
                                                        uint32_t* __restrict__ seeds, uint32_t* __restrict__ ctrl,

@@ -357,3 +357,27 @@ def test_frame_batches_render_the_serial_frames(scene2, synth_small, monkeypatch
             r.close()
         assert (out["1"] == out[forced]).all() and (out[("1", "sync")] == out[(forced, "sync")]).all()
     monkeypatch.delenv("RTX_BATCH", raising=False)
+
+
+def test_wide_walk_tests_exactly_the_reference_leaf_set(scene1, synth_small):
+    """The default traversal (own 4-wide tree, byte boxes, no order, no culling) must intersect a primitive iff the
+    reference does: a leaf is tested iff its own box passes. Counted on the device: the number of
+    primitive intersections per bounce equals that of the reference-topology walk, and the total equals the oracle's
+    count (src/ThreadedShader.cpp:362-368 executions) for the same frames."""
+    for s in (scene1, synth_small):
+        d, cam = s.desc(), s.camera
+        counts = {}
+        for name, trav in (("wide", _capi.TRAVERSE_WIDE), ("exact", _capi.TRAVERSE_EXACT)):
+            r = HIPShader(s, traversal=trav, count_stats=True)
+            for f in range(3):
+                r.frame_counter = f
+                r.Render(None)
+            c = r.counters()
+            counts[name] = (list(c.leafTests), list(c.raysPerBounce), list(c.hitsPerBounce))
+            r.close()
+        assert counts["wide"] == counts["exact"]
+        px = np.zeros((d.height, d.width, 4), np.float32)
+        leaf = 0
+        for f in range(3):
+            leaf += oracle.render(d, cam, f, px, 8, stats=2).leafTests
+        assert sum(counts["wide"][0]) == leaf
