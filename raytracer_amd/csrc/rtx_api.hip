@@ -154,7 +154,7 @@ struct Flat {
     // arrays; the host only plans them: for every leaf position its box and tie-break rank, and the index maps the
     // reference-topology records need. (leaf / shade above are filled on the host only for the linear list.)
     std::vector<int2> leafPlan;
-    std::vector<int32_t> slotOf, posOf;
+    std::vector<int32_t, rtxbuild::NoInitAlloc<int32_t>> slotOf, posOf;
     size_t numLeaves = 0, numInner = 0;
     bool deviceEmit = false;
 };
@@ -241,33 +241,30 @@ int flatten(const RtxSceneDesc& s, bool useBVH, bool wantFast, bool wantQuant, i
     PhaseClock clock;
     const uint64_t nObj = s.numObjects, nBox = s.numBoxes;
     ErrorSlot err;
-    parallel_for(nObj, nthreads, [&](uint64_t b, uint64_t e) {
-        for (uint64_t i = b; i < e; ++i) {
-            const int32_t m = s.objects[i].materialID;
-            if (m < 0 || (uint64_t)m >= s.numMaterials) { err.set("object " + std::to_string(i) + ": materialID out of range"); return; }
-        }
-    });
-    if (err.any()) return fail(err.msg);
-    {   // shape statistics for the culling slack (rtx_traverse.h)
+    {   // one pass over the objects: material range + shape statistics for the culling slack (rtx_traverse.h)
         std::atomic<uint64_t> tris{0}, slivers{0};
         parallel_for(nObj, nthreads, [&](uint64_t b, uint64_t e) {
             uint64_t t = 0, sl = 0;
             for (uint64_t i = b; i < e; ++i) {
                 const RtxObject& o = s.objects[i];
+                const int32_t m = o.materialID;
+                if (m < 0 || (uint64_t)m >= s.numMaterials) { err.set("object " + std::to_string(i) + ": materialID out of range"); return; }
                 if (o.type != RTX_TRIANGLE) continue;
                 const RtxVec4 &A = o.vertices[0], &B = o.vertices[1], &C = o.vertices[2];
                 const double e1[3] = {(double)B.x - A.x, (double)B.y - A.y, (double)B.z - A.z};
                 const double e2[3] = {(double)C.x - A.x, (double)C.y - A.y, (double)C.z - A.z};
                 const double e3[3] = {(double)C.x - B.x, (double)C.y - B.y, (double)C.z - B.z};
                 const double n[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
-                const double area2 = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);       // 2 x area
+                // sliver: longest edge^2 > 32 x (2 x area), compared squared (no square root per triangle); also NaN / zero area
+                const double area2sq = n[0] * n[0] + n[1] * n[1] + n[2] * n[2];
                 const double l2 = std::max({e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2], e2[0] * e2[0] + e2[1] * e2[1] + e2[2] * e2[2],
                                             e3[0] * e3[0] + e3[1] * e3[1] + e3[2] * e3[2]});
                 ++t;
-                if (!(l2 <= 32.0 * area2)) ++sl;          // also NaN / zero area
+                if (!(l2 * l2 <= 1024.0 * area2sq)) ++sl;
             }
             tris += t; slivers += sl;
         });
+        if (err.any()) return fail(err.msg);
         f.sliverFraction = tris ? (double)slivers / (double)tris : 0.0;
     }
     if (!useBVH) {
@@ -281,29 +278,51 @@ int flatten(const RtxSceneDesc& s, bool useBVH, bool wantFast, bool wantQuant, i
     }
     if (nBox > 0x7fffffffull) return fail("too many boxes");
     // index of every box inside its own array (inner / leaf), in box order
-    std::vector<int32_t> slotOf(nBox);
-    std::vector<int32_t> leafBox;        // reference leaf index -> box index
+    std::vector<int32_t, rtxbuild::NoInitAlloc<int32_t>> slotOf(nBox);
+    std::vector<int32_t, rtxbuild::NoInitAlloc<int32_t>> leafBox;        // reference leaf index -> box index
     int32_t nInner = 0, nLeaf = 0;
-    for (uint64_t b = 0; b < nBox; ++b) {
-        const RtxBoundingBox& box = s.boxes[b];
-        if (box.objectID != -1) {
-            if (box.objectID < 0 || (uint64_t)box.objectID >= nObj) return fail("box " + std::to_string(b) + ": objectID out of range");
-            slotOf[b] = nLeaf++;
-        } else {
-            slotOf[b] = nInner++;
-        }
+    {   // leaves and inner boxes are numbered in box order: count per chunk, prefix, then number (all threads; the
+        // boxes are 64 bytes each and this is the first of two streaming reads of them)
+        const int T = (nthreads > 1 && nBox >= 65536) ? nthreads : 1;
+        const uint64_t per = (nBox + (uint64_t)T - 1) / (uint64_t)T;
+        std::vector<int32_t> leavesIn((size_t)T + 1, 0);
+        auto chunk = [&](int t, uint64_t& b0, uint64_t& b1) { b0 = std::min(nBox, (uint64_t)t * per); b1 = std::min(nBox, b0 + per); };
+        auto run = [&](auto&& body) {
+            std::vector<std::thread> pool;
+            for (int t = 1; t < T; ++t) pool.emplace_back([&body, t]() { body(t); });
+            body(0);
+            for (auto& th : pool) th.join();
+        };
+        run([&](int t) {
+            uint64_t b0, b1; chunk(t, b0, b1);
+            int32_t c = 0;
+            for (uint64_t b = b0; b < b1; ++b) {
+                const int32_t id = s.boxes[b].objectID;
+                if (id != -1) { if (id < 0 || (uint64_t)id >= nObj) { err.set("box " + std::to_string(b) + ": objectID out of range"); return; } ++c; }
+            }
+            leavesIn[(size_t)t + 1] = c;
+        });
+        if (err.any()) return fail(err.msg);
+        for (int t = 0; t < T; ++t) leavesIn[(size_t)t + 1] += leavesIn[(size_t)t];
+        nLeaf = leavesIn[(size_t)T]; nInner = (int32_t)(nBox - (uint64_t)nLeaf);
+        leafBox.resize((size_t)nLeaf);
+        run([&](int t) {
+            uint64_t b0, b1; chunk(t, b0, b1);
+            int32_t l = leavesIn[(size_t)t], in = (int32_t)b0 - l;
+            for (uint64_t b = b0; b < b1; ++b) {
+                if (s.boxes[b].objectID != -1) { leafBox[(size_t)l] = (int32_t)b; slotOf[b] = l++; }
+                else slotOf[b] = in++;
+            }
+        });
     }
-    leafBox.resize((size_t)nLeaf);
-    parallel_for(nBox, nthreads, [&](uint64_t b0, uint64_t b1) {
-        for (uint64_t b = b0; b < b1; ++b) if (s.boxes[b].objectID != -1) leafBox[(size_t)slotOf[b]] = (int32_t)b;
-    });
     // depth + tree check (every box reached at most once) + nesting check (parent contains child) + well-formed
     // boxes + the leaves' tie-break ranks (emit_leaf). The walk starts breadth-first on one thread; once the frontier
     // is wide enough its subtrees are walked depth-first on all threads (a box reached twice — by any two walkers —
     // is an error). The frontier keeps the left-to-right order of the tree, a subtree's walker numbers its leaves
     // locally, and a prefix sum over the frontier turns that into the global left-first rank.
     if (nLeaf >= (1 << 28)) return fail("too many leaves (2^28 or more)");
-    std::vector<int32_t> rankLocal((size_t)nLeaf, 0), rankPart((size_t)nLeaf, 0);   // per leaf: right-first index inside its part, part
+    std::vector<int32_t, rtxbuild::NoInitAlloc<int32_t>> rankLocal((size_t)nLeaf), rankPart((size_t)nLeaf);   // per leaf: right-first index inside its part, part
+    parallel_for((uint64_t)nLeaf, nthreads, [&](uint64_t k0, uint64_t k1) { for (uint64_t k = k0; k < k1; ++k) { rankLocal[k] = 0; rankPart[k] = 0; } });
     std::vector<int64_t> partBase;                                                   // per frontier entry: leaves left of it
     std::vector<int32_t> partCount;
     {
@@ -400,8 +419,8 @@ int flatten(const RtxSceneDesc& s, bool useBVH, bool wantFast, bool wantQuant, i
     }
     f.seconds[0] = clock.lap("validate + walk boxes");
     // own tree over the same leaf boxes (DESIGN.md "Topology freedom")
-    std::vector<uint32_t> order((size_t)nLeaf);
-    for (int32_t k = 0; k < nLeaf; ++k) order[k] = (uint32_t)k;
+    rtxbuild::Raw<uint32_t> order((size_t)nLeaf);
+    parallel_for((uint64_t)nLeaf, nthreads, [&](uint64_t k0, uint64_t k1) { for (uint64_t k = k0; k < k1; ++k) order[k] = (uint32_t)k; });
     if (wantFast && f.nested && nLeaf >= 2) {
         rtxbuild::Raw<rtxbuild::Box> prim((size_t)nLeaf);
         parallel_for((uint64_t)nLeaf, nthreads, [&](uint64_t k0, uint64_t k1) {
@@ -437,7 +456,7 @@ int flatten(const RtxSceneDesc& s, bool useBVH, bool wantFast, bool wantQuant, i
         // RTX_TRAVERSE_WIDE: byte boxes, children regrouped (inner first, leaves as neighbours): a new leaf order
         std::vector<uint32_t> newToOld;
         if (rtxbuild::quantize4(f.fast, f.qnodes, newToOld, nthreads) && newToOld.size() == (size_t)nLeaf) {
-            std::vector<uint32_t> order2((size_t)nLeaf);
+            rtxbuild::Raw<uint32_t> order2((size_t)nLeaf);
             parallel_for((uint64_t)nLeaf, nthreads, [&](uint64_t p0, uint64_t p1) { for (uint64_t p = p0; p < p1; ++p) order2[p] = order[newToOld[p]]; });
             order.swap(order2);
             rtxbuild::Raw<rtxbuild::Node4>().swap(f.fast);
@@ -449,7 +468,7 @@ int flatten(const RtxSceneDesc& s, bool useBVH, bool wantFast, bool wantQuant, i
         f.seconds[1] += clock.lap("quantise nodes");
     }
     // leaves in the new order; reference leaf index -> position. The records themselves are written on the device.
-    std::vector<int32_t> posOf((size_t)nLeaf);
+    std::vector<int32_t, rtxbuild::NoInitAlloc<int32_t>> posOf((size_t)nLeaf);     // a permutation: every entry is written below
     f.leafPlan.resize((size_t)nLeaf);
     parallel_for((uint64_t)nLeaf, nthreads, [&](uint64_t p0, uint64_t p1) {
         for (uint64_t p = p0; p < p1; ++p) {
@@ -488,6 +507,7 @@ struct RawUpload {
     std::thread worker;
     hipError_t err = hipSuccess;
     bool started = false;
+    size_t freeAtStart = 0;              // free device memory before the raw arrays were allocated (RtxInfo.deviceBytes)
     static hipError_t copy(int dev, const RtxSceneDesc* sc, float4** dObj, float4** dBox) {
         hipError_t e = hipSetDevice(dev);
         const size_t ob = (size_t)sc->numObjects * sizeof(RtxObject), bb = (size_t)sc->numBoxes * sizeof(RtxBoundingBox);
@@ -499,7 +519,11 @@ struct RawUpload {
     }
     void start(int dev, const RtxSceneDesc* sc) {
         device = dev; started = true;
-        worker = std::thread([this, dev, sc]() { err = copy(dev, sc, &dObjects, &dBoxes); });
+        worker = std::thread([this, dev, sc]() {
+            size_t total = 0;
+            if (hipSetDevice(dev) != hipSuccess || hipMemGetInfo(&freeAtStart, &total) != hipSuccess) freeAtStart = 0;
+            err = copy(dev, sc, &dObjects, &dBoxes);
+        });
     }
     hipError_t wait() { if (worker.joinable()) worker.join(); return err; }
     void release() {
@@ -765,8 +789,10 @@ int rtx_create(const RtxSceneDesc* scene, const RtxConfig* cfgIn, RtxRenderer** 
     PhaseClock createClock;
     // the raw arrays start for the (first) device now; the records are written there once the leaf order is known
     RawUpload raw;
-    if (useBVH) raw.start(cfg.numDevices > 1 ? cfg.devices[0] : cfg.device, scene);
-    if (flatten(*scene, useBVH, wantFast, wantQuant, 16, flat)) return 1;
+    if (useBVH && !getenv("RTX_UPLOAD_LATE")) raw.start(cfg.numDevices > 1 ? cfg.devices[0] : cfg.device, scene);
+    int buildThreads = 16;
+    if (const char* e = getenv("RTX_BUILD_THREADS")) buildThreads = std::max(1, std::min(64, atoi(e)));      // experiments
+    if (flatten(*scene, useBVH, wantFast, wantQuant, buildThreads, flat)) return 1;
     createClock.lap("flatten");
     if (useBVH && flat.maxDepth > 62) return fail("BVH deeper than 62 levels is not supported (the reference's own stack holds 32)");
 
@@ -833,6 +859,10 @@ static int build_renderer(const RtxSceneDesc* scene, const RtxConfig& cfg, const
     }
     size_t freeBefore = 0, freeAfter = 0, totalMem = 0;
     CREATE_HIP(hipMemGetInfo(&freeBefore, &totalMem));
+    if (raw && raw->started && raw->device == r->device) {      // the raw arrays are on this device already (and go away again below)
+        raw->wait();
+        if (raw->freeAtStart) freeBefore = raw->freeAtStart;
+    }
     for (int i = 0; i < kRing; ++i) for (int k = 0; k < kEvents; ++k) CREATE_HIP(hipEventCreate(&r->ev[i][k]));
 
     // tiles: tile t (row-major over the tile grid) belongs to rank t % worldSize

@@ -20,6 +20,7 @@
 #include <cstdint>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <thread>
 #include <utility>
 #include <vector>
@@ -188,12 +189,10 @@ struct SahBuilder {
         return nodeIdx;
     }
 
-    // builds the subtree over order[begin,end) whose centroids lie in `cbounds`; returns its ref
-    // (>= 0 inner index, < 0 ~leafPosition)
-    int32_t build(uint32_t begin, uint32_t end, int32_t nodeIdx, int depth, const Box& cbounds, int threads, Box& outBox, int& outDepth) {
+    // one binned split of items[begin,end) (more than kSweepNode of them, centroids inside `cbounds`): partitions the
+    // range, returns the first item of the right side and both sides' centroid bounds
+    uint32_t split_node(uint32_t begin, uint32_t end, const Box& cbounds, int threads, Box& cl, Box& cr) {
         const uint32_t n = end - begin;
-        if (n == 1) { outBox = items[begin].box(); outDepth = depth; return ~(int32_t)begin; }
-        if (n <= kSweepNode) return build_small(begin, end, nodeIdx, depth, outBox, outDepth);
         Split sp; bool any = false;
         for (int a = 0; a < 3; ++a) {
             const float ext = cbounds.hi[a] - cbounds.lo[a];
@@ -227,7 +226,7 @@ struct SahBuilder {
             }
         }
         uint32_t mid;
-        Box cl = empty_box(), cr = empty_box();
+        cl = empty_box(); cr = empty_box();
         if (bestAxis >= 0) {
             const int a = bestAxis;
             const float lo = sp.lo[a], scale = sp.scale[a];
@@ -283,16 +282,52 @@ struct SahBuilder {
                 grow_centroid(i < mid ? cl : cr, items[i]);
             }
         }
+        return mid;
+    }
+
+    // builds the subtree over items[begin,end) whose centroids lie in `cbounds`; returns its ref
+    // (>= 0 inner index, < 0 ~leafPosition)
+    int32_t build(uint32_t begin, uint32_t end, int32_t nodeIdx, int depth, const Box& cbounds, int threads, Box& outBox, int& outDepth) {
+        const uint32_t n = end - begin;
+        if (n == 1) { outBox = items[begin].box(); outDepth = depth; return ~(int32_t)begin; }
+        if (n <= kSweepNode) return build_small(begin, end, nodeIdx, depth, outBox, outDepth);
+        Box cl, cr;
+        const uint32_t mid = split_node(begin, end, cbounds, threads, cl, cr);
         const uint32_t nl = mid - begin;
         const int32_t leftIdx = nodeIdx + 1, rightIdx = nodeIdx + (int32_t)nl;   // left subtree has nl-1 inner nodes
         Box bl, br; int dl = 0, dr = 0; int32_t rl, rr;
         if (threads > 1 && n > 8192) {
-            // threads are shared out by size, so that both sides finish together
+            // threads are shared out by size, so that both sides finish together — as far as whole threads can be
+            // shared out; a side that finishes early takes subtrees off the other's hands meanwhile (below)
             int tl = (int)((double)threads * nl / n + 0.5);
             tl = tl < 1 ? 1 : (tl > threads - 1 ? threads - 1 : tl);
-            std::thread t([&]() { rl = build(begin, mid, leftIdx, depth + 1, cl, tl, bl, dl); });
+            std::atomic<bool> leftDone{false}, rightDone{false};
+            std::thread t([&]() {
+                rl = build(begin, mid, leftIdx, depth + 1, cl, tl, bl, dl);
+                leftDone.store(true, std::memory_order_release);
+                while (!rightDone.load(std::memory_order_acquire)) if (!help_one()) std::this_thread::yield();
+            });
             rr = build(mid, end, rightIdx, depth + 1, cr, threads - tl, br, dr);
+            rightDone.store(true, std::memory_order_release);
+            while (!leftDone.load(std::memory_order_acquire)) if (!help_one()) std::this_thread::yield();
             t.join();
+        } else if (stealing && n > kStealGrain) {
+            // one thread, a large subtree: the right side is offered to threads that have run out of work
+            Offer o{mid, end, rightIdx, depth + 1, &cr, &br, &dr, &rr, {0}};
+            { std::lock_guard<std::mutex> g(offerMutex); offers.push_back(&o); offerCount.store((int)offers.size(), std::memory_order_relaxed); }
+            rl = build(begin, mid, leftIdx, depth + 1, cl, 1, bl, dl);
+            bool mine = false;
+            {
+                std::lock_guard<std::mutex> g(offerMutex);
+                if (o.state.load(std::memory_order_relaxed) == 0) {
+                    for (size_t k = offers.size(); k-- > 0;) if (offers[k] == &o) { offers.erase(offers.begin() + (long)k); break; }
+                    offerCount.store((int)offers.size(), std::memory_order_relaxed);
+                    o.state.store(1, std::memory_order_relaxed);
+                    mine = true;
+                }
+            }
+            if (mine) rr = build(mid, end, rightIdx, depth + 1, cr, 1, br, dr);
+            else while (o.state.load(std::memory_order_acquire) != 2) if (!help_one()) std::this_thread::yield();
         } else {
             rl = build(begin, mid, leftIdx, depth + 1, cl, 1, bl, dl);
             rr = build(mid, end, rightIdx, depth + 1, cr, 1, br, dr);
@@ -302,6 +337,41 @@ struct SahBuilder {
         outDepth = std::max(dl, dr);
         return nodeIdx;
     }
+
+    // ---- subtrees on offer ------------------------------------------------------------------------------------------
+    // Whole threads cannot be shared out evenly (3 threads over a 50 / 50 split leave one side twice the time of the
+    // other, and a scene's few huge primitives make the top splits lopsided), so a thread that builds a subtree of
+    // more than kStealGrain primitives alone puts the right side of each split on offer before it descends into the
+    // left, and takes it back afterwards unless a thread with nothing left to do has taken it: those are the threads
+    // that would otherwise sit in join(). 0.56 -> see tools/build_time on a scene's own leaf boxes.
+    static const uint32_t kStealGrain = 1u << 15;
+    struct Offer { uint32_t begin, end; int32_t nodeIdx; int depth; const Box* cbounds; Box* outBox; int* outDepth; int32_t* ref; std::atomic<int> state; };   // 0 offered, 1 taken, 2 done
+    bool stealing = false;
+    std::mutex offerMutex;
+    std::vector<Offer*> offers;           // oldest (largest) first
+    std::atomic<int> offerCount{0};
+    bool help_one() {
+        static thread_local int nesting = 0;
+        if (!stealing || nesting >= 4 || offerCount.load(std::memory_order_relaxed) == 0) return false;          // every level of help is a recursion of its own on this thread's stack
+        Offer* o = nullptr;
+        {
+            std::lock_guard<std::mutex> g(offerMutex);
+            if (offers.empty()) return false;
+            o = offers.front(); offers.erase(offers.begin());
+            offerCount.store((int)offers.size(), std::memory_order_relaxed);
+            o->state.store(1, std::memory_order_relaxed);
+        }
+        ++nesting;
+        *o->ref = build(o->begin, o->end, o->nodeIdx, o->depth, *o->cbounds, 1, *o->outBox, *o->outDepth);
+        --nesting;
+        o->state.store(2, std::memory_order_release);
+        return true;
+    }
+
+    // (Tried instead of sharing the threads out between the two sides of every split: all nodes of 128 K primitives or
+    // more split one after the other on all threads, the subtrees below them from a queue, largest first. Balanced,
+    // but the scratch-array partition of the parallel split then runs on six levels instead of four: 0.45 s against
+    // 0.31 s at 10 M primitives on 16 threads.)
 };
 
 // order[] in: any permutation of 0..n-1; out: leaf order of the new tree.
@@ -325,7 +395,8 @@ inline int32_t build_sah(const Box* prim, uint32_t n, uint32_t* order, Node* nod
         });
         for (const Box& pbx : part) grow(cb, pbx);
     }
-    SahBuilder b{items.data(), nodes, scratch.data()};
+    SahBuilder b;
+    b.items = items.data(); b.nodes = nodes; b.scratch = scratch.data(); b.stealing = nthreads > 1;
     Box root; int depth = 0;
     const int32_t ref = b.build(0, n, 0, 0, cb, nthreads < 1 ? 1 : nthreads, root, depth);
     SahBuilder::parallel_chunks(0, n, nthreads < 1 ? 1 : (n < 65536 ? 1 : nthreads), [&](int, uint32_t b, uint32_t e) { for (uint32_t i = b; i < e; ++i) order[i] = items[i].id; });
@@ -668,17 +739,23 @@ inline bool quantize4(const Raw<Node4>& in, Raw<NodeQ>& out, std::vector<uint32_
                 int eb = 1;                                           // biased exponent of the grid step, 1..254
                 if (ext > 0.0 && std::isfinite(ext)) { int ex; std::frexp(ext / 255.0, &ex); eb = std::min(254, std::max(1, ex + 127)); }   // 2^ex >= ext / 255
                 uint32_t wl = 0, wh = 0;
+                // The grid step is a power of two, so position / step is a multiplication by its (exact) reciprocal, and
+                // the positions are not negative, so floor is the cast. The decoded plane the kernel computes is
+                // fl32(q * step + lo); q * step + lo rounded to double instead (one rounding of the exact sum, q * step
+                // being exact) lies on the same side of the child's plane or rounds onto it exactly when the float does,
+                // so "double <= clo" implies "float <= clo" (and likewise >= chi): no libm call per plane.
                 for (;;) {
-                    const float step = i2f(eb << 23);
+                    const double step = (double)i2f(eb << 23), inv = std::ldexp(1.0, 127 - eb), dlo = (double)lo;
                     bool fits = true; wl = 0; wh = 0;
                     for (int j = 0; j < nc && fits; ++j) {
                         const float clo = q[8 * a + p.slot[j]], chi = q[8 * a + 4 + p.slot[j]];
-                        int ql = (int)std::floor(((double)clo - (double)lo) / (double)step);
-                        ql = std::min(255, std::max(0, ql));
-                        while (ql > 0 && std::fmaf((float)ql, step, lo) > clo) --ql;            // decoded plane must not lie inside
-                        int qh = (int)std::ceil(((double)chi - (double)lo) / (double)step);
-                        qh = std::max(0, qh);
-                        while (qh <= 255 && std::fmaf((float)qh, step, lo) < chi) ++qh;
+                        const double xl = ((double)clo - dlo) * inv, xh = ((double)chi - dlo) * inv;
+                        if (!(xh <= 255.0)) { fits = false; break; }
+                        int ql = xl >= 255.0 ? 255 : (int)xl;
+                        while (ql > 0 && (double)ql * step + dlo > (double)clo) --ql;           // decoded plane must not lie inside
+                        int qh = (int)xh;
+                        if ((double)qh < xh) ++qh;
+                        while (qh <= 255 && (double)qh * step + dlo < (double)chi) ++qh;
                         if (qh > 255) { fits = false; break; }
                         wl |= (uint32_t)ql << (8 * j); wh |= (uint32_t)qh << (8 * j);
                     }

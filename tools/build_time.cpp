@@ -12,10 +12,16 @@ int main(int argc, char** argv) {
     std::mt19937 rng(1);
     auto uni = [&](float lo, float hi) { return lo + (hi - lo) * (float)(rng() >> 8) * (1.0f / 16777216.0f); };
     Raw<Box> prim(n);
+    if (argc > 3) {            // boxes from a file (n x 6 floats: lo.xyz hi.xyz), e.g. a scene's leaf boxes in the caller's order
+        FILE* f = fopen(argv[3], "rb");
+        if (!f || fread(prim.data(), sizeof(Box), n, f) != n) { fprintf(stderr, "cannot read %u boxes from %s\n", n, argv[3]); return 1; }
+        fclose(f);
+    } else {
     const uint32_t side = (uint32_t)std::sqrt((double)n);
     for (uint32_t i = 0; i < n; ++i) {
         const float cx = (i % side) * 0.5f + uni(0, .3f), cy = (i / side) * 0.5f + uni(0, .3f), cz = std::sin(cx * 0.05f) * 20 + uni(0, .2f), s = 0.3f;
         prim[i].lo[0] = cx - s; prim[i].lo[1] = cy - s; prim[i].lo[2] = cz - s; prim[i].hi[0] = cx + s; prim[i].hi[1] = cy + s; prim[i].hi[2] = cz + s;
+    }
     }
     for (int rep = 0; rep < 2; ++rep) {
         std::vector<uint32_t> order(n); for (uint32_t i = 0; i < n; ++i) order[i] = i;
