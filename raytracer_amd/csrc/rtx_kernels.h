@@ -448,25 +448,33 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_trace_q(DevScene sc, const float4
                 }
             }
             if (!drained) {
+                // Straight-line refill: every lane loads a queue entry (a lane that takes none reads the run's first
+                // one), both loads leave together, and the lane state is replaced by selects. Written as "if (this lane
+                // takes a ray) { load origin; if (valid) { load direction; ... } }" the block cost two memory round
+                // trips one after the other and about seventy register copies around its branches — a whole traversal
+                // pass per refill, which is why refilling early (few idle lanes) used to lose.
                 const uint32_t avail = rend - rcur;
                 const uint32_t take = (uint32_t)nIdle < avail ? (uint32_t)nIdle : avail;
                 const uint32_t rank = (uint32_t)__popcll(idle & laneLt);
-                if (!busy && rank < take) {
-                    q = rcur + rank;
-                    const float4 o = rqO[q], d = rqD[q];
-                    dx = d.x; dy = d.y; dz = d.z;
-                    if (d.w != 0.0f) {
-                        hitLeaf[q] = RTX_INVALID_SLOT;     // slot outside the image, or a hole in a bounce queue
-                    } else if (lane_is_clean(o.x, o.y, o.z, dx, dy, dz)) {
-                        r = q_ray(o.x, o.y, o.z, 1.0f / dx, 1.0f / dy, 1.0f / dz);
-                        best.t = INFINITY; best.leaf = -1; best.box = -1;
-                        st.nsp = 0; st.nbase = 0; st.lsp = 0;
-                        nodeCur = RTX_QENTRY(0, 1); leafCur = 0;
-                        busy = true;
-                    } else {
-                        slowList[atomicAdd(&ctrl[RTX_CTRL_SLOW(countIdx)], 1u)] = q;
-                    }
-                }
+                const bool mine = !busy && rank < take;
+                const uint32_t qn = mine ? rcur + rank : rcur;
+                const float4 o = rqO[qn], d = rqD[qn];
+                const bool hole = d.w != 0.0f;             // slot outside the image, or a hole in a bounce queue
+                const bool clean = lane_is_clean(o.x, o.y, o.z, d.x, d.y, d.z);
+                const QRay nr = q_ray(o.x, o.y, o.z, 1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                const bool start = mine && !hole && clean;
+                q = mine ? qn : q;
+                dx = start ? d.x : dx; dy = start ? d.y : dy; dz = start ? d.z : dz;
+                r.ox = start ? nr.ox : r.ox; r.oy = start ? nr.oy : r.oy; r.oz = start ? nr.oz : r.oz;
+                r.ix = start ? nr.ix : r.ix; r.iy = start ? nr.iy : r.iy; r.iz = start ? nr.iz : r.iz;
+                r.nx = start ? nr.nx : r.nx; r.ny = start ? nr.ny : r.ny; r.nz = start ? nr.nz : r.nz;
+                best.t = start ? INFINITY : best.t; best.leaf = start ? -1 : best.leaf; best.box = start ? -1 : best.box;
+                st.nsp = start ? 0 : st.nsp; st.nbase = start ? 0 : st.nbase; st.lsp = start ? 0 : st.lsp;
+                nodeCur = start ? RTX_QENTRY(0, 1) : nodeCur; leafCur = start ? 0 : leafCur;
+                busy = busy || start;
+                if (mine && hole) hitLeaf[qn] = RTX_INVALID_SLOT;
+                // axis-parallel / non-finite ray: k_trace_slow walks the reference topology for it
+                if (mine && !hole && !clean) slowList[atomicAdd(&ctrl[RTX_CTRL_SLOW(countIdx)], 1u)] = qn;
                 rcur += take;
             }
             continue;

@@ -32,6 +32,7 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, uint32_t seed) {
                 if (OP == 11) asm volatile("v_min_f32 %0, %1, %2" : "=v"(f[i]) : "v"(f[(i + 1) & 7]), "v"(f[(i + 2) & 7]));
                 if (OP == 12) asm volatile("v_sub_f32 %0, %1, %2" : "=v"(f[i]) : "v"(f[(i + 1) & 7]), "v"(f[(i + 2) & 7]));
                 if (OP == 13) asm volatile("v_mul_f32 %0, %1, %2" : "=v"(f[i]) : "v"(f[(i + 1) & 7]), "v"(f[(i + 2) & 7]));
+                if (OP == 16) asm volatile("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(f[i]) : "v"(x[(i + 1) & 7]), "v"(f[(i + 2) & 7]), "v"(f[(i + 3) & 7]));
             }
         }
     }
@@ -44,9 +45,9 @@ int main() {
     hipDeviceProp_t prop; CHECK(hipGetDeviceProperties(&prop, 0));
     const int cus = prop.multiProcessorCount; const double ghz = prop.clockRate * 1e-6;
     const int iters = 4096, blocks = cus * 8;     // 8 blocks x 4 waves per CU = 8 waves per SIMD
-    const char* names[] = {"v_fma_f32", "v_cvt_f32_ubyte1", "v_perm_b32", "v_cvt_f32_u32", "v_max3_f32", "v_cndmask_b32 vcc (vcc never written: artefact)", "v_pk_fma_f32", "v_bfe_u32", "v_cndmask_e64 sgpr", "v_cmp_e64", "v_cmp+v_cndmask", "v_min_f32", "v_sub_f32", "v_mul_f32", "cmp_e32;nop;cndmask_e32 (3 instr)", "cmp_e32;mov;mov;cndmask_e32 (4 instr)"};
+    const char* names[] = {"v_fma_f32", "v_cvt_f32_ubyte1", "v_perm_b32", "v_cvt_f32_u32", "v_max3_f32", "v_cndmask_b32 vcc (vcc never written: artefact)", "v_pk_fma_f32", "v_bfe_u32", "v_cndmask_e64 sgpr", "v_cmp_e64", "v_cmp+v_cndmask", "v_min_f32", "v_sub_f32", "v_mul_f32", "cmp_e32;nop;cndmask_e32 (3 instr)", "cmp_e32;mov;mov;cndmask_e32 (4 instr)", "v_fma_mix_f32 (f16 hi, f32, f32)"};
     hipEvent_t t0, t1; CHECK(hipEventCreate(&t0)); CHECK(hipEventCreate(&t1));
-    for (int op = 0; op < 16; ++op) {
+    for (int op = 0; op < 17; ++op) {
         float best = 1e30f;
         for (int rep = 0; rep < 3; ++rep) {
             CHECK(hipEventRecord(t0, 0));
@@ -67,6 +68,7 @@ int main() {
             case 13: hipLaunchKernelGGL(k<13>, dim3(blocks), dim3(256), 0, 0, out, iters, 3u); break;
             case 14: hipLaunchKernelGGL(k<14>, dim3(blocks), dim3(256), 0, 0, out, iters, 3u); break;
             case 15: hipLaunchKernelGGL(k<15>, dim3(blocks), dim3(256), 0, 0, out, iters, 3u); break;
+            case 16: hipLaunchKernelGGL(k<16>, dim3(blocks), dim3(256), 0, 0, out, iters, 3u); break;
             }
             CHECK(hipEventRecord(t1, 0)); CHECK(hipEventSynchronize(t1));
             float ms; CHECK(hipEventElapsedTime(&ms, t0, t1)); if (rep && ms < best) best = ms;
