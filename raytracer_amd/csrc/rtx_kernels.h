@@ -403,8 +403,13 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_trace_refill(DevScene sc, const f
 
 // RTX_TRAVERSE_WIDE's bounce launch: the lane-refill loop of k_trace_refill around the unordered two-list pass of
 // rtx_traverse.h (q_pass). Same queue protocol, same outputs.
+#if defined(RTX_TRACEQ_WAVES)
+#define RTX_TRACEQ_ATTR __attribute__((amdgpu_waves_per_eu(RTX_TRACEQ_WAVES, RTX_TRACEQ_WAVES)))
+#else
+#define RTX_TRACEQ_ATTR
+#endif
 template <bool COUNT, int BOUNCE, bool BIG>
-__global__ __launch_bounds__(RTX_BLOCK) void k_trace_q(DevScene sc, const float4* __restrict__ rqO, const float4* __restrict__ rqD,
+__global__ __launch_bounds__(RTX_BLOCK) RTX_TRACEQ_ATTR void k_trace_q(DevScene sc, const float4* __restrict__ rqO, const float4* __restrict__ rqD,
                                                        float* __restrict__ hitT, int* __restrict__ hitLeaf,
                                                        uint32_t* __restrict__ ctrl, unsigned long long* __restrict__ stats,
                                                        uint32_t* __restrict__ slowList, uint32_t fixedCount, int workIdx) {

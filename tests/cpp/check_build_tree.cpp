@@ -127,6 +127,7 @@ static void run(uint32_t n, unsigned seed, int threads, bool degenerate) {
 
 int main() {
     run(2, 1, 1, false); run(3, 2, 1, false); run(5, 3, 2, false); run(1000, 4, 4, false); run(200000, 5, 8, false);
+    run(600000, 7, 5, false);      // uneven thread shares: subtrees change hands between threads (SahBuilder offers)
     run(4097, 6, 4, true);
     Raw<Node4> one; Box b; for (int a = 0; a < 3; ++a) { b.lo[a] = 1; b.hi[a] = 2; }
     single_leaf_node4(&b, one);
