@@ -70,25 +70,32 @@ def sync_only(args):
     from raytracer_amd.scene import synthetic_scene
     ntri, w, h, textured, grid = WORKLOADS[args.workload]
     scene = synthetic_scene(ntri, w, h, seed=12345, textured=textured, nthreads=16, grid=grid)
-    shader = HIPShader(scene, device=0, traversal={"wide": _capi.TRAVERSE_WIDE, "culled": _capi.TRAVERSE_CULLED, "exact": _capi.TRAVERSE_EXACT}[args.traversal])
-    px = np.zeros((shader.height, shader.width, 4), dtype=np.float32)
-    for i in range(2):
-        shader.frame_counter = i
-        shader.Render(px)
-    shader.reset_counters()
-    n = max(4, min(args.steps, 32))
-    t0 = time.perf_counter()
-    for i in range(n):
-        shader.frame_counter = 2 + i            # src/WindowManager.cpp:156-157
-        shader.Render(px)
-    dt = time.perf_counter() - t0
-    c = shader.counters()
-    info = shader.info()
-    print(json.dumps({"ms_per_step": dt / n * 1e3, "mrays_per_s": float(c.rays) / dt / 1e6, "frames": n,
-                      "device_ms_per_frame": c.totalMs / max(1, c.frames),
-                      "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"), "hw_queues_seen": info.hwQueues,
-                      "pattern": "rtx_render(pixels) per frame, synchronous, 16 B/pixel copied to a pageable host array every frame"}))
-    shader.close()
+    trav = {"wide": _capi.TRAVERSE_WIDE, "culled": _capi.TRAVERSE_CULLED, "exact": _capi.TRAVERSE_EXACT}[args.traversal]
+    res = {}
+    for key, look in (("no_look_ahead", -1), ("default", 0)):
+        shader = HIPShader(scene, device=0, traversal=trav, look_ahead=look)
+        px = np.zeros((shader.height, shader.width, 4), dtype=np.float32)
+        for i in range(3):
+            shader.frame_counter = i
+            shader.Render(px)
+        c0 = shader.counters()                  # (no reset here: it would make the renderer forget the loop it has seen)
+        n = max(4, min(args.steps, 32))
+        t0 = time.perf_counter()
+        for i in range(n):
+            shader.frame_counter = 3 + i            # src/WindowManager.cpp:156-157
+            shader.Render(px)
+        dt = time.perf_counter() - t0
+        c = shader.counters()
+        info = shader.info()
+        res[key] = {"ms_per_step": dt / n * 1e3, "mrays_per_s": float(c.rays - c0.rays) / dt / 1e6, "frames": n, "look_ahead": info.lookAhead,
+                    "hw_queues_seen": info.hwQueues}
+        shader.close()
+    out = dict(res["default"])
+    out.update({"without_look_ahead": {"ms_per_step": res["no_look_ahead"]["ms_per_step"], "mrays_per_s": res["no_look_ahead"]["mrays_per_s"]},
+                "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"),
+                "pattern": "rtx_render(pixels) per frame, synchronous, 16 B/pixel copied to a pageable host array every frame; "
+                           "look_ahead = frames the library starts before they are asked for (RtxConfig.lookAhead, same results)"})
+    print(json.dumps(out))
 
 
 def main():

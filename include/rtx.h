@@ -156,6 +156,14 @@ typedef struct RtxConfig {
                               for the whole group, so IFrameRender::Render(Color*) drives up to 8 GPUs with the
                               reference's Main.cpp untouched. rank/worldSize must be 0/1 then. The same ordinal may
                               appear twice (rehearsal on one GPU). 0 or 1: one device, `device`. */
+    int32_t lookAhead;     /* rtx_render WITH pixels hands the frame back before it returns, so calls cannot overlap —
+                              unless the renderer starts the next frames before they are asked for. After two calls in
+                              a row for (camera, n) and (camera, n + 1) — the reference's loop, src/WindowManager.cpp:
+                              154-158 — it queues up to `lookAhead` following frames (everything but their update of the
+                              running mean) before it copies the current one out; the next call either asks for the
+                              first of them or they are dropped unused. Results and counters are the same either way;
+                              a wrong guess costs device time only. 0 -> up to 3, at most framesInFlight - 1 (2 with
+                              HIP's default 4 hardware queues); -1 -> never. */
 } RtxConfig;
 
 typedef struct RtxCounters {
@@ -195,7 +203,7 @@ typedef struct RtxInfo {
     uint64_t deviceBytes;      /* device memory held by this renderer */
     double   createSeconds[4]; /* validate + walk boxes, own-tree build, record emission, upload + allocation */
     int32_t  devices;          /* members of the device group this handle stands for (1: a single renderer) */
-    int32_t  _pad;
+    int32_t  lookAhead;        /* frames rtx_render(pixels) starts ahead (RtxConfig.lookAhead as resolved) */
 } RtxInfo;
 
 typedef struct RtxRenderer RtxRenderer;

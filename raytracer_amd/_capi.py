@@ -36,7 +36,7 @@ class Config(C.Structure):
     _fields_ = [("device", C.c_int32), ("rank", C.c_int32), ("worldSize", C.c_int32),
                 ("tileW", C.c_int32), ("tileH", C.c_int32), ("traversal", C.c_int32),
                 ("countStats", C.c_int32), ("framesInFlight", C.c_int32),
-                ("numDevices", C.c_int32), ("devices", C.c_int32 * 8)]
+                ("numDevices", C.c_int32), ("devices", C.c_int32 * 8), ("lookAhead", C.c_int32)]
 
 
 class Counters(C.Structure):
@@ -53,7 +53,7 @@ class Info(C.Structure):
                 ("refTreeDepth", C.c_int32), ("wideTreeDepth", C.c_int32), ("stackEntries", C.c_int32),
                 ("leaves", C.c_uint64), ("innerNodes", C.c_uint64), ("wideNodes", C.c_uint64),
                 ("sliverFraction", C.c_double), ("deviceBytes", C.c_uint64), ("createSeconds", C.c_double * 4),
-                ("devices", C.c_int32), ("_pad", C.c_int32)]
+                ("devices", C.c_int32), ("lookAhead", C.c_int32)]
 
 
 # numpy mirrors of the reference PODs (sizes/offsets as in include/rtx.h)

@@ -15,6 +15,7 @@
 #include <cstring>
 #include <string>
 #include <atomic>
+#include <deque>
 #include <mutex>
 #include <thread>
 #include <chrono>
@@ -72,6 +73,7 @@ struct RtxRenderer {
     float4 *dLight = nullptr, *dAcc = nullptr, *dFb = nullptr;
     uint32_t *dSeeds = nullptr, *dCtrl = nullptr;
     unsigned long long* dStats = nullptr;
+    unsigned long long* curStats = nullptr;    // where the launches of the current set count: dStats, or the context's look-ahead counters
 
     // tiles
     int tileW = 64, tileH = 32, tilesX = 0, tilesY = 0;
@@ -101,6 +103,7 @@ struct RtxRenderer {
         uint32_t* hCounts = nullptr;       // pinned: the frame's queue lengths, copied back without a sync
         hipEvent_t countsReady = nullptr;
         bool countsPending = false;
+        unsigned long long* dStatsAhead = nullptr;   // work counters of a look-ahead frame, added to dStats when the frame is asked for
     };
     std::vector<FrameCtx> ctx;
     int active = 0;
@@ -134,6 +137,19 @@ struct RtxRenderer {
     char* hStage = nullptr;         // page-locked staging for delivering the frame to a (pageable) host array
     size_t hStageBytes = 0;
     std::vector<hipEvent_t> stageEv;
+    hipStream_t copyStream = nullptr;   // frame delivery, so that it waits for the frame's resolve only
+
+    // Look-ahead for the synchronous pattern (the reference's loop: Render(pixels); frameCounter++, src/WindowManager.cpp:154-158).
+    // A call that has to hand the frame back cannot overlap with the next one — unless the next one is started before it
+    // is asked for. When two calls in a row asked for (camera, n) and (camera, n + 1), frames n + 2 (and n + 3) are queued on
+    // the next contexts before frame n + 1 is copied out: everything but their resolve, with work counters of their own.
+    // The next call either asks for exactly the oldest of them (its resolve is queued, its counters are added, and the
+    // look-ahead is topped up) or for something else (they are dropped: their launches run out unused, nothing they
+    // wrote is ever read).
+    struct Ahead { RtxCamera cam{}; uint32_t fc = 0; int ctx = -1; DevBatch bt{}; };
+    std::deque<Ahead> ahead;            // frames started ahead, oldest first: consecutive frame counters, one camera
+    bool haveLastSync = false; RtxCamera lastSyncCam{}; uint32_t lastSyncFc = 0; int syncStreak = 0;
+    int lookAhead = 0;                  // how many frames are started ahead (0: never)
 };
 
 // ---------------------------------------------------------------------------------
@@ -600,6 +616,7 @@ void activate(RtxRenderer* r, int i) {
     r->dHitT = c.dHitT; r->dHitLeaf = c.dHitLeaf; r->dLight = c.dLight; r->dAcc = c.dAcc;
     r->dSeeds = c.dSeeds; r->dCtrl = c.dCtrl; r->dSlow = c.dSlow; r->dSpill = c.dSpill;
     r->sc.spill = c.dSpill;
+    r->curStats = r->dStats;
 }
 
 // A persistent grid costs ~70 ns per block to launch and drain whatever it finds to do (2048 blocks: 0.15 ms),
@@ -644,19 +661,19 @@ template <int MODE>
 void launch_primary(RtxRenderer* r, const DevBatch& bt, int workIdx) {
     if (r->cfg.countStats)
         hipLaunchKernelGGL((k_primary<MODE, true>), dim3(r->launchTrace), dim3(RTX_BLOCK), r->ldsTrace, r->stream, r->sc, bt, r->dTiles,
-                           r->dRqO[0], r->dRqD[0], r->dHitT, r->dHitLeaf, r->dSeeds, r->dCtrl, r->dStats, workIdx);
+                           r->dRqO[0], r->dRqD[0], r->dHitT, r->dHitLeaf, r->dSeeds, r->dCtrl, r->curStats, workIdx);
     else
         hipLaunchKernelGGL((k_primary<MODE, false>), dim3(r->launchTrace), dim3(RTX_BLOCK), r->ldsTrace, r->stream, r->sc, bt, r->dTiles,
-                           r->dRqO[0], r->dRqD[0], r->dHitT, r->dHitLeaf, r->dSeeds, r->dCtrl, r->dStats, workIdx);
+                           r->dRqO[0], r->dRqD[0], r->dHitT, r->dHitLeaf, r->dSeeds, r->dCtrl, r->curStats, workIdx);
 }
 template <int MODE>
 void launch_trace(RtxRenderer* r, const float4* o, const float4* d, int countIdx, int workIdx, uint32_t fixedCount) {
     if (r->cfg.countStats)
         hipLaunchKernelGGL((k_trace<MODE, true>), dim3(r->launchTrace), dim3(RTX_BLOCK), r->ldsTrace, r->stream, r->sc, o, d,
-                           r->dHitT, r->dHitLeaf, r->dCtrl, r->dStats, fixedCount, countIdx, workIdx);
+                           r->dHitT, r->dHitLeaf, r->dCtrl, r->curStats, fixedCount, countIdx, workIdx);
     else
         hipLaunchKernelGGL((k_trace<MODE, false>), dim3(r->launchTrace), dim3(RTX_BLOCK), r->ldsTrace, r->stream, r->sc, o, d,
-                           r->dHitT, r->dHitLeaf, r->dCtrl, r->dStats, fixedCount, countIdx, workIdx);
+                           r->dHitT, r->dHitLeaf, r->dCtrl, r->curStats, fixedCount, countIdx, workIdx);
 }
 void dispatch_primary(RtxRenderer* r, const DevBatch& bt, int workIdx) {
     // Bounce 0 is coherent (one 8x8 pixel block per wave): it keeps one ray per lane per batch, fused with
@@ -679,10 +696,10 @@ void dispatch_trace(RtxRenderer* r, const float4* o, const float4* d, int countI
         case (B) * 4 + ((C) ? 2 : 0) + ((G) ? 1 : 0):                                                                          \
             if (quant)                                                                                                         \
             hipLaunchKernelGGL((k_trace_q<C, B, G>), dim3(r->launchTrace), dim3(RTX_BLOCK), r->ldsTrace, r->stream, r->sc,     \
-                               o, d, r->dHitT, r->dHitLeaf, r->dCtrl, r->dStats, r->dSlow, fixedCount, workIdx);               \
+                               o, d, r->dHitT, r->dHitLeaf, r->dCtrl, r->curStats, r->dSlow, fixedCount, workIdx);               \
             else                                                                                                               \
             hipLaunchKernelGGL((k_trace_refill<C, B, G>), dim3(r->launchTrace), dim3(RTX_BLOCK), r->ldsTrace, r->stream, r->sc, \
-                               o, d, r->dHitT, r->dHitLeaf, r->dCtrl, r->dStats, r->dSlow, fixedCount, workIdx);               \
+                               o, d, r->dHitT, r->dHitLeaf, r->dCtrl, r->curStats, r->dSlow, fixedCount, workIdx);               \
             break;
 #define RTX_REFILL_BOUNCE(B) RTX_REFILL_CASE(B, false, false) RTX_REFILL_CASE(B, false, true) RTX_REFILL_CASE(B, true, false) RTX_REFILL_CASE(B, true, true)
             RTX_REFILL_BOUNCE(0) RTX_REFILL_BOUNCE(1) RTX_REFILL_BOUNCE(2) RTX_REFILL_BOUNCE(3)
@@ -691,10 +708,10 @@ void dispatch_trace(RtxRenderer* r, const float4* o, const float4* d, int countI
         }
         if (r->cfg.countStats)
             hipLaunchKernelGGL((k_trace_slow<true>), dim3(r->numCUs), dim3(RTX_BLOCK), r->ldsSlow, r->stream, r->sc, o, d,
-                               r->dHitT, r->dHitLeaf, r->dCtrl, r->dStats, r->dSlow, countIdx);
+                               r->dHitT, r->dHitLeaf, r->dCtrl, r->curStats, r->dSlow, countIdx);
         else
             hipLaunchKernelGGL((k_trace_slow<false>), dim3(r->numCUs), dim3(RTX_BLOCK), r->ldsSlow, r->stream, r->sc, o, d,
-                               r->dHitT, r->dHitLeaf, r->dCtrl, r->dStats, r->dSlow, countIdx);
+                               r->dHitT, r->dHitLeaf, r->dCtrl, r->curStats, r->dSlow, countIdx);
         return;
     }
     if (r->mode == RTX_MODE_LINEAR) launch_trace<RTX_MODE_LINEAR>(r, o, d, countIdx, workIdx, fixedCount);
@@ -732,9 +749,11 @@ void rtx_destroy(RtxRenderer* r) {
         if (c.resolved) hipEventDestroy(c.resolved);
         if (c.countsReady) hipEventDestroy(c.countsReady);
         if (c.hCounts) hipHostFree(c.hCounts);
+        if (c.dStatsAhead) hipFree(c.dStatsAhead);
         if (c.stream) hipStreamDestroy(c.stream);
     }
     if (r->hStage) hipHostFree(r->hStage);
+    if (r->copyStream) { hipStreamSynchronize(r->copyStream); hipStreamDestroy(r->copyStream); }
     for (hipEvent_t e : r->stageEv) hipEventDestroy(e);
     void* ptrs[] = {r->dFast, r->dQNodes, r->dInner, r->dLeaf, r->dShade, r->dMaterials, r->dTexInfo, r->dTexels, r->dTiles, r->dFb, r->dStats};
     for (void* p : ptrs) if (p) hipFree(p);
@@ -977,11 +996,16 @@ static int build_renderer(const RtxSceneDesc* scene, const RtxConfig& cfg, const
         CREATE_HIP(hipMalloc((void**)&c.dAcc, n * sizeof(float4)));
         CREATE_HIP(hipMalloc((void**)&c.dSeeds, n * sizeof(uint32_t)));
         CREATE_HIP(hipMalloc((void**)&c.dCtrl, RTX_CTRL_WORDS * sizeof(uint32_t)));
+        CREATE_HIP(hipMalloc((void**)&c.dStatsAhead, RTX_STAT_WORDS * sizeof(unsigned long long)));
         if (culled) {
             CREATE_HIP(hipMalloc((void**)&c.dSlow, nq * sizeof(uint32_t)));
             CREATE_HIP(hipMalloc((void**)&c.dSpill, (size_t)r->sc.stackDepth * r->gridTrace * RTX_BLOCK * sizeof(int2)));
         }
     }
+    CREATE_HIP(hipStreamCreateWithFlags(&r->copyStream, hipStreamNonBlocking));
+    r->lookAhead = cfg.lookAhead < 0 ? 0 : std::min(cfg.lookAhead > 0 ? cfg.lookAhead : 3, depth - 1);       // 2 with HIP's default 4 hardware queues (3 contexts)
+    if (const char* e = getenv("RTX_LOOKAHEAD")) r->lookAhead = std::max(0, std::min(atoi(e), depth - 1));
+    if (cfg.worldSize != 1) r->lookAhead = 0;       // a rank of a process group delivers through the gather, once per batch
     activate(r, 0);
     for (int b = 0; b < 4; ++b) r->queueHint[b] = r->numSlots * (uint32_t)r->batch;
     set_grids(r, r->numSlots * (uint32_t)r->batch);
@@ -991,6 +1015,7 @@ static int build_renderer(const RtxSceneDesc* scene, const RtxConfig& cfg, const
         in.traversal = r->linear ? RTX_TRAVERSE_EXACT : (culled ? (std::isinf(r->sc.cullSlack) ? RTX_TRAVERSE_WIDE : RTX_TRAVERSE_CULLED) : RTX_TRAVERSE_EXACT);
         in.linear = r->linear ? 1 : 0;
         in.devices = 1;
+        in.lookAhead = r->lookAhead;
         in.bigNodes = (r->mode == RTX_MODE_CULLED_BIG || r->mode == RTX_MODE_WIDEQ_BIG) ? 1 : 0;
         in.cullSlack = culled ? r->sc.cullSlack : INFINITY;
         in.framesInFlight = depth; in.framesPerBatch = r->batch; in.hwQueues = hwQueues;
@@ -1013,11 +1038,28 @@ static int build_renderer(const RtxSceneDesc* scene, const RtxConfig& cfg, const
     return 0;
 }
 
+// the running mean takes the frames in order: a batch's resolve waits for the resolve queued before it
+static int queue_resolve(RtxRenderer* r, const DevBatch& bt) {
+    if (r->lastResolved >= 0 && r->lastResolved != r->active)
+        HIP_TRY(hipStreamWaitEvent(r->stream, r->ctx[r->lastResolved].resolved, 0));
+    if (r->numSlots)
+        hipLaunchKernelGGL(k_resolve, dim3((r->numSlots + RTX_BLOCK - 1) / RTX_BLOCK), dim3(RTX_BLOCK), 0, r->stream, bt, r->dTiles,
+                           r->dAcc, r->dFb);
+    HIP_TRY(hipEventRecord(r->ctx[r->active].resolved, r->stream));
+    r->lastResolved = r->active;
+    return 0;
+}
+
 // One set of launches for `count` frames (1 <= count <= r->batch), in call order.
-static int render_batch(RtxRenderer* r, const std::pair<RtxCamera, uint32_t>* frames, int count, bool primaryOnly) {
+// ahead: a look-ahead frame (RtxRenderer::Ahead) — everything but the resolve, counted apart.
+static int render_batch(RtxRenderer* r, const std::pair<RtxCamera, uint32_t>* frames, int count, bool primaryOnly, bool ahead = false) {
     HIP_TRY(hipSetDevice(r->device));
     // batches take the contexts in turn; a context's stream orders a batch after the one that used it last
     activate(r, (int)(r->frameSeq++ % r->ctx.size()));
+    if (ahead) {
+        r->curStats = r->ctx[r->active].dStatsAhead;
+        HIP_TRY(hipMemsetAsync(r->curStats, 0, RTX_STAT_WORDS * sizeof(unsigned long long), r->stream));
+    }
     const int slot = r->ringPos;
     r->ringPos = (r->ringPos + 1) % kRing;
     finish_timing(r, (slot + kRing - kLag) % kRing);     // the batch queued kLag batches ago has long finished
@@ -1048,18 +1090,11 @@ static int render_batch(RtxRenderer* r, const std::pair<RtxCamera, uint32_t>* fr
             }
             hipLaunchKernelGGL(k_shade, dim3(r->launchShade), dim3(RTX_BLOCK), 0, r->stream, r->sc, bt, r->dTiles, b, r->linear ? 1 : 0,
                                r->dRqO[in], r->dRqD[in], r->dHitT, r->dHitLeaf, r->dRqO[in ^ 1], r->dRqD[in ^ 1],
-                               r->dLight, r->dAcc, r->dSeeds, r->dCtrl, r->dStats, 2 * b + 1);
+                               r->dLight, r->dAcc, r->dSeeds, r->dCtrl, r->curStats, 2 * b + 1);
             HIP_TRY(hipEventRecord(ev[2 * b + 2], r->stream));
             in ^= 1;
         }
-        // the running mean takes the frames in order: this batch's resolve waits for the previous batch's
-        if (r->lastResolved >= 0 && r->lastResolved != r->active)
-            HIP_TRY(hipStreamWaitEvent(r->stream, r->ctx[r->lastResolved].resolved, 0));
-        if (r->numSlots)
-            hipLaunchKernelGGL(k_resolve, dim3((r->numSlots + RTX_BLOCK - 1) / RTX_BLOCK), dim3(RTX_BLOCK), 0, r->stream, bt, r->dTiles,
-                               r->dAcc, r->dFb);
-        HIP_TRY(hipEventRecord(r->ctx[r->active].resolved, r->stream));
-        r->lastResolved = r->active;
+        if (!ahead && queue_resolve(r, bt)) return 1;
         {
             RtxRenderer::FrameCtx& c = r->ctx[r->active];
             if (!c.countsPending && count == r->batch) {       // hints describe full batches
@@ -1070,15 +1105,35 @@ static int render_batch(RtxRenderer* r, const std::pair<RtxCamera, uint32_t>* fr
         }
         HIP_TRY(hipEventRecord(ev[kEvents - 1], r->stream));
         r->pending[slot] = true;
-        r->totals.frames += (uint64_t)count;
-        r->primaryRays += r->localPixels * (uint64_t)count;
+        if (ahead) {
+            r->ahead.push_back(RtxRenderer::Ahead{frames[0].first, frames[0].second, r->active, bt});
+        } else {
+            r->totals.frames += (uint64_t)count;
+            r->primaryRays += r->localPixels * (uint64_t)count;
+        }
     }
+    r->curStats = r->dStats;
     HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// the look-ahead frame is the one that is asked for: its resolve, its counters
+static int take_ahead(RtxRenderer* r) {
+    HIP_TRY(hipSetDevice(r->device));
+    activate(r, r->ahead.front().ctx);
+    if (queue_resolve(r, r->ahead.front().bt)) return 1;
+    hipLaunchKernelGGL(k_add_stats, dim3(1), dim3(64), 0, r->stream, r->dStats, r->ctx[r->active].dStatsAhead, RTX_STAT_WORDS);
+    HIP_TRY(hipGetLastError());
+    r->totals.frames += 1;
+    r->primaryRays += r->localPixels;
+    r->ahead.pop_front();
     return 0;
 }
 
 // renders whatever rtx_render(pixels = NULL) has collected
 static int flush_queued(RtxRenderer* r) {
+    // whatever comes next is not the frame that was started ahead (render_one checks for that before it gets here)
+    r->ahead.clear(); r->haveLastSync = false; r->syncStreak = 0;
     if (r->queued.empty()) return 0;
     std::vector<std::pair<RtxCamera, uint32_t>> q;
     q.swap(r->queued);
@@ -1102,42 +1157,53 @@ static int render_frame(RtxRenderer* r, const RtxCamera* cam, uint32_t fc, bool 
 static int dev_to_host(RtxRenderer* r, const void* devSrc, void* hostDst, size_t bytes);
 static int fb_to_host(RtxRenderer* r, float* pixels, size_t bytes) { return dev_to_host(r, r->dFb, pixels, bytes); }
 
+// The caller's array is ordinary pageable memory (page-locking it per call costs more than the copy, and caching a
+// registration across calls would outlive the array): frames are copied through a page-locked staging buffer of the
+// renderer in 8 MiB pieces, and four host threads move each piece on as soon as it has landed.
+// 133.7 MB at 4K: 8.5 ms through the runtime's pageable path, 3.0 ms this way.
+static const size_t kStagePiece = (size_t)8 << 20;
+
+// queues the copy of src[0, bytes) into the staging buffer on `stream`, one event per piece
+static int stage_queue(RtxRenderer* r, hipStream_t stream, const char* src, size_t bytes) {
+    if (r->hStage && r->hStageBytes < bytes) { hipHostFree(r->hStage); r->hStage = nullptr; }
+    if (!r->hStage) { HIP_TRY(hipHostMalloc((void**)&r->hStage, bytes, hipHostMallocDefault)); r->hStageBytes = bytes; }
+    const size_t n = (bytes + kStagePiece - 1) / kStagePiece;
+    while (r->stageEv.size() < n) { hipEvent_t e; HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming)); r->stageEv.push_back(e); }
+    for (size_t k = 0; k < n; ++k) {
+        const size_t off = k * kStagePiece, len = std::min(kStagePiece, bytes - off);
+        HIP_TRY(hipMemcpyAsync(r->hStage + off, src + off, len, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipEventRecord(r->stageEv[k], stream));
+    }
+    return 0;
+}
+// staging buffer -> dst, piece by piece as they land
+static int stage_deliver(RtxRenderer* r, char* dst, size_t bytes) {
+    const size_t n = (bytes + kStagePiece - 1) / kStagePiece;
+    const int T = 4;
+    std::atomic<int> failed{0};
+    auto mover = [&](int t) {
+        if (hipSetDevice(r->device) != hipSuccess) { failed = 1; return; }
+        for (size_t k = (size_t)t; k < n; k += T) {
+            if (hipEventSynchronize(r->stageEv[k]) != hipSuccess) { failed = 1; return; }
+            const size_t off = k * kStagePiece, len = std::min(kStagePiece, bytes - off);
+            memcpy(dst + off, r->hStage + off, len);
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < T; ++t) pool.emplace_back(mover, t);
+    mover(0);
+    for (auto& th : pool) th.join();
+    if (failed) return fail("device-to-host copy of the frame failed");
+    return 0;
+}
+
 // device array of this renderer -> caller's (pageable) host array
 static int dev_to_host(RtxRenderer* r, const void* devSrc, void* hostDst, size_t bytes) {
-    char* dst = (char*)hostDst; const char* src = (const char*)devSrc;
-    if (bytes >= ((size_t)8 << 20) && !getenv("RTX_PLAIN_COPY")) {
-        // The caller's array is ordinary pageable memory (page-locking it per call costs more than the copy, and
-        // caching a registration across calls would outlive the array): copy through a page-locked staging buffer
-        // of the renderer in 8 MiB pieces and let four host threads move each piece on as soon as it has landed.
-        // 133.7 MB at 4K: 8.5 ms through the runtime's pageable path, 3.0 ms this way.
-        const size_t piece = (size_t)8 << 20, n = (bytes + piece - 1) / piece;
-        if (r->hStage && r->hStageBytes < bytes) { hipHostFree(r->hStage); r->hStage = nullptr; }
-        if (!r->hStage) { HIP_TRY(hipHostMalloc((void**)&r->hStage, bytes, hipHostMallocDefault)); r->hStageBytes = bytes; }
-        while (r->stageEv.size() < n) { hipEvent_t e; HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming)); r->stageEv.push_back(e); }
-        for (size_t k = 0; k < n; ++k) {
-            const size_t off = k * piece, len = std::min(piece, bytes - off);
-            HIP_TRY(hipMemcpyAsync(r->hStage + off, src + off, len, hipMemcpyDeviceToHost, r->stream));
-            HIP_TRY(hipEventRecord(r->stageEv[k], r->stream));
-        }
-        const int T = 4;
-        std::atomic<int> failed{0};
-        auto mover = [&](int t) {
-            if (hipSetDevice(r->device) != hipSuccess) { failed = 1; return; }
-            for (size_t k = (size_t)t; k < n; k += T) {
-                if (hipEventSynchronize(r->stageEv[k]) != hipSuccess) { failed = 1; return; }
-                const size_t off = k * piece, len = std::min(piece, bytes - off);
-                memcpy(dst + off, r->hStage + off, len);
-            }
-        };
-        std::vector<std::thread> pool;
-        for (int t = 1; t < T; ++t) pool.emplace_back(mover, t);
-        mover(0);
-        for (auto& th : pool) th.join();
-        if (failed) return fail("device-to-host copy of the frame failed");
-        return 0;
-    } else {
-        HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, r->stream));
+    if (bytes >= kStagePiece && !getenv("RTX_PLAIN_COPY")) {
+        if (stage_queue(r, r->stream, (const char*)devSrc, bytes)) return 1;
+        return stage_deliver(r, (char*)hostDst, bytes);
     }
+    HIP_TRY(hipMemcpyAsync(hostDst, devSrc, bytes, hipMemcpyDeviceToHost, r->stream));
     HIP_TRY(hipStreamSynchronize(r->stream));
     return 0;
 }
@@ -1197,6 +1263,27 @@ static int render_one(RtxRenderer* r, const RtxCamera* camera, uint32_t frameCou
         r->queued.emplace_back(*camera, frameCounter);
         if ((int)r->queued.size() >= r->batch) return flush_queued(r);
         return 0;
+    }
+    const size_t fbBytes = (size_t)r->width * r->height * sizeof(float4);
+    if (pixels_rgba && r->lookAhead > 0 && r->batch == 1 && !getenv("RTX_PLAIN_COPY")) {
+        // the synchronous pattern, with look-ahead (RtxRenderer::Ahead)
+        const bool predicted = r->haveLastSync && frameCounter == r->lastSyncFc + 1u && memcmp(camera, &r->lastSyncCam, sizeof(RtxCamera)) == 0;
+        const int streak = predicted ? r->syncStreak + 1 : 0;
+        if (!r->ahead.empty() && r->ahead.front().fc == frameCounter && memcmp(camera, &r->ahead.front().cam, sizeof(RtxCamera)) == 0) {
+            if (take_ahead(r)) return 1;
+        } else {
+            if (render_frame(r, camera, frameCounter, false)) return 1;      // drops a look-ahead frame that was not asked for
+        }
+        r->haveLastSync = true; r->lastSyncCam = *camera; r->lastSyncFc = frameCounter; r->syncStreak = streak;
+        const int mine = r->active;
+        while (streak >= 1 && (int)r->ahead.size() < r->lookAhead) {
+            const std::pair<RtxCamera, uint32_t> next(*camera, frameCounter + 1u + (uint32_t)r->ahead.size());
+            if (render_batch(r, &next, 1, false, true)) return 1;
+        }
+        // delivery waits for this frame's resolve, not for what was started after it
+        HIP_TRY(hipStreamWaitEvent(r->copyStream, r->ctx[mine].resolved, 0));
+        if (stage_queue(r, r->copyStream, (const char*)r->dFb, fbBytes)) return 1;
+        return stage_deliver(r, (char*)pixels_rgba, fbBytes);
     }
     if (render_frame(r, camera, frameCounter, false)) return 1;
     if (pixels_rgba) return copy_out(r, pixels_rgba);

@@ -636,6 +636,12 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_resolve(DevBatch bt, const int2* 
     fb[pix] = make_float4(res.x, res.y, res.z, res.w);
 }
 
+// counters of a look-ahead frame into the renderer's (rtx_api.hip take_ahead); other streams add to dst at the same time
+__global__ void k_add_stats(unsigned long long* __restrict__ dst, const unsigned long long* __restrict__ src, int n) {
+    const int i = (int)threadIdx.x;
+    if (i < n && src[i]) atomicAdd(&dst[i], src[i]);
+}
+
 // ---- probes -------------------------------------------------------------------
 __global__ void k_hits_to_ids(DevScene sc, DevFrame fr, const int2* __restrict__ tiles, const int* __restrict__ hitLeaf, int* __restrict__ ids) {
     uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;

@@ -381,3 +381,52 @@ def test_wide_walk_tests_exactly_the_reference_leaf_set(scene1, synth_small):
         for f in range(3):
             leaf += oracle.render(d, cam, f, px, 8, stats=2).leafTests
         assert sum(counts["wide"][0]) == leaf
+
+
+def test_look_ahead_of_the_synchronous_loop_is_invisible(scene2, monkeypatch):
+    """rtx_render(pixels) starts the frames it expects next (same camera, frameCounter + 1, + 2, ...) before it copies the
+    current one out (rtx_api.hip RtxRenderer::Ahead). Whatever the caller does next — the expected frame, another frame
+    counter, another camera, queued frames, upload / clear / probes in between — images and work counters must be those of
+    a renderer that never looks ahead, bit for bit, and the oracle's."""
+    from raytracer_amd.scene import orbit
+    d, cam = scene2.desc(), scene2.camera
+    cam2 = type(cam).from_buffer_copy(cam); orbit(cam2, 30.0, 10.0, radius=2500.0)
+    start = np.random.default_rng(5).random((d.height, d.width, 4), dtype=np.float32)
+    # (op, argument): r = synchronous Render(pixels), q = queued Render(NULL), the rest are the calls that may come in between
+    script = [("r", (cam, 0)), ("r", (cam, 1)), ("r", (cam, 2)), ("r", (cam, 3)),          # the loop: look-ahead kicks in and is used
+              ("r", (cam, 7)),                                                               # a jump: what was started is dropped
+              ("r", (cam, 8)), ("r", (cam, 9)), ("r", (cam2, 10)),                           # another camera
+              ("r", (cam2, 11)), ("r", (cam2, 12)), ("upload", start), ("r", (cam2, 13)),    # the accumulator is replaced while frames are ahead
+              ("r", (cam2, 14)), ("q", (cam2, 15)), ("q", (cam2, 16)), ("r", (cam2, 17)),    # queued frames in between
+              ("r", (cam2, 18)), ("ids", (cam, 3)), ("r", (cam2, 19)), ("r", (cam2, 20)),
+              ("clear", None), ("r", (cam, 0)), ("r", (cam, 1)), ("r", (cam, 2)), ("counters", None), ("r", (cam, 3))]
+    runs = {}
+    for ahead in ("0", "2"):
+        monkeypatch.setenv("RTX_LOOKAHEAD", ahead)
+        r = HIPShader(scene2)
+        px = np.zeros((d.height, d.width, 4), np.float32)
+        log = []
+        for op, arg in script:
+            if op in ("r", "q"):
+                r.frame_counter = arg[1]
+                r.Render(px if op == "r" else None, arg[0])
+                if op == "r": log.append(px.copy())
+            elif op == "upload": r.upload(arg)
+            elif op == "clear": r.clear()
+            elif op == "ids": log.append(r.primary_hits(arg[1], arg[0]).copy())
+            elif op == "counters":
+                c = r.counters(); log.append(np.array([c.frames] + list(c.raysPerBounce) + list(c.hitsPerBounce), np.int64))
+        c = r.counters()
+        log.append(np.array([c.frames] + list(c.raysPerBounce) + list(c.hitsPerBounce), np.int64))
+        runs[ahead] = log
+        r.close()
+    assert len(runs["0"]) == len(runs["2"])
+    for a, b in zip(runs["0"], runs["2"]):
+        assert a.dtype == b.dtype and (a.view(np.uint32) == b.view(np.uint32)).all()
+    frames = sum(1 for op, _ in script if op in ("r", "q"))
+    assert runs["2"][-1][0] == frames and runs["2"][-1][1] == frames * d.width * d.height      # frames dropped unused are not counted
+    # and the oracle's image for the last stretch (after the clear)
+    want = np.zeros((d.height, d.width, 4), np.float32)
+    for fc in range(4):
+        oracle.render(d, cam, fc, want, 8)
+    check_fb(runs["2"][-2], want)
