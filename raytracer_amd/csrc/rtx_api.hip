@@ -69,7 +69,7 @@ struct RtxRenderer {
     uint32_t* dTexels = nullptr;
     int2* dTiles = nullptr;
     float4 *dRqO[2] = {nullptr, nullptr}, *dRqD[2] = {nullptr, nullptr};
-    float* dHitT = nullptr; int* dHitLeaf = nullptr;
+    int2* dHit = nullptr;                 // per queue entry: (bits of the hit distance, leaf)
     float4 *dLight = nullptr, *dAcc = nullptr, *dFb = nullptr;
     uint32_t *dSeeds = nullptr, *dCtrl = nullptr;
     unsigned long long* dStats = nullptr;
@@ -95,7 +95,7 @@ struct RtxRenderer {
     struct FrameCtx {
         hipStream_t stream = nullptr;
         float4 *dRqO[2] = {nullptr, nullptr}, *dRqD[2] = {nullptr, nullptr};
-        float* dHitT = nullptr; int* dHitLeaf = nullptr;
+        int2* dHit = nullptr;                 // per queue entry: (bits of the hit distance, leaf)
         float4 *dLight = nullptr, *dAcc = nullptr;
         uint32_t *dSeeds = nullptr, *dCtrl = nullptr, *dSlow = nullptr;
         int2* dSpill = nullptr;
@@ -613,7 +613,7 @@ void activate(RtxRenderer* r, int i) {
     r->active = i;
     r->stream = c.stream;
     for (int k = 0; k < 2; ++k) { r->dRqO[k] = c.dRqO[k]; r->dRqD[k] = c.dRqD[k]; }
-    r->dHitT = c.dHitT; r->dHitLeaf = c.dHitLeaf; r->dLight = c.dLight; r->dAcc = c.dAcc;
+    r->dHit = c.dHit; r->dLight = c.dLight; r->dAcc = c.dAcc;
     r->dSeeds = c.dSeeds; r->dCtrl = c.dCtrl; r->dSlow = c.dSlow; r->dSpill = c.dSpill;
     r->sc.spill = c.dSpill;
     r->curStats = r->dStats;
@@ -661,19 +661,19 @@ template <int MODE>
 void launch_primary(RtxRenderer* r, const DevBatch& bt, int workIdx) {
     if (r->cfg.countStats)
         hipLaunchKernelGGL((k_primary<MODE, true>), dim3(r->launchTrace), dim3(RTX_BLOCK), r->ldsTrace, r->stream, r->sc, bt, r->dTiles,
-                           r->dRqO[0], r->dRqD[0], r->dHitT, r->dHitLeaf, r->dSeeds, r->dCtrl, r->curStats, workIdx);
+                           r->dRqO[0], r->dRqD[0], r->dHit, r->dSeeds, r->dCtrl, r->curStats, workIdx);
     else
         hipLaunchKernelGGL((k_primary<MODE, false>), dim3(r->launchTrace), dim3(RTX_BLOCK), r->ldsTrace, r->stream, r->sc, bt, r->dTiles,
-                           r->dRqO[0], r->dRqD[0], r->dHitT, r->dHitLeaf, r->dSeeds, r->dCtrl, r->curStats, workIdx);
+                           r->dRqO[0], r->dRqD[0], r->dHit, r->dSeeds, r->dCtrl, r->curStats, workIdx);
 }
 template <int MODE>
 void launch_trace(RtxRenderer* r, const float4* o, const float4* d, int countIdx, int workIdx, uint32_t fixedCount) {
     if (r->cfg.countStats)
         hipLaunchKernelGGL((k_trace<MODE, true>), dim3(r->launchTrace), dim3(RTX_BLOCK), r->ldsTrace, r->stream, r->sc, o, d,
-                           r->dHitT, r->dHitLeaf, r->dCtrl, r->curStats, fixedCount, countIdx, workIdx);
+                           r->dHit, r->dCtrl, r->curStats, fixedCount, countIdx, workIdx);
     else
         hipLaunchKernelGGL((k_trace<MODE, false>), dim3(r->launchTrace), dim3(RTX_BLOCK), r->ldsTrace, r->stream, r->sc, o, d,
-                           r->dHitT, r->dHitLeaf, r->dCtrl, r->curStats, fixedCount, countIdx, workIdx);
+                           r->dHit, r->dCtrl, r->curStats, fixedCount, countIdx, workIdx);
 }
 void dispatch_primary(RtxRenderer* r, const DevBatch& bt, int workIdx) {
     // Bounce 0 is coherent (one 8x8 pixel block per wave): it keeps one ray per lane per batch, fused with
@@ -696,10 +696,10 @@ void dispatch_trace(RtxRenderer* r, const float4* o, const float4* d, int countI
         case (B) * 4 + ((C) ? 2 : 0) + ((G) ? 1 : 0):                                                                          \
             if (quant)                                                                                                         \
             hipLaunchKernelGGL((k_trace_q<C, B, G>), dim3(r->launchTrace), dim3(RTX_BLOCK), r->ldsTrace, r->stream, r->sc,     \
-                               o, d, r->dHitT, r->dHitLeaf, r->dCtrl, r->curStats, r->dSlow, fixedCount, workIdx);               \
+                               o, d, r->dHit, r->dCtrl, r->curStats, r->dSlow, fixedCount, workIdx);               \
             else                                                                                                               \
             hipLaunchKernelGGL((k_trace_refill<C, B, G>), dim3(r->launchTrace), dim3(RTX_BLOCK), r->ldsTrace, r->stream, r->sc, \
-                               o, d, r->dHitT, r->dHitLeaf, r->dCtrl, r->curStats, r->dSlow, fixedCount, workIdx);               \
+                               o, d, r->dHit, r->dCtrl, r->curStats, r->dSlow, fixedCount, workIdx);               \
             break;
 #define RTX_REFILL_BOUNCE(B) RTX_REFILL_CASE(B, false, false) RTX_REFILL_CASE(B, false, true) RTX_REFILL_CASE(B, true, false) RTX_REFILL_CASE(B, true, true)
             RTX_REFILL_BOUNCE(0) RTX_REFILL_BOUNCE(1) RTX_REFILL_BOUNCE(2) RTX_REFILL_BOUNCE(3)
@@ -708,10 +708,10 @@ void dispatch_trace(RtxRenderer* r, const float4* o, const float4* d, int countI
         }
         if (r->cfg.countStats)
             hipLaunchKernelGGL((k_trace_slow<true>), dim3(r->numCUs), dim3(RTX_BLOCK), r->ldsSlow, r->stream, r->sc, o, d,
-                               r->dHitT, r->dHitLeaf, r->dCtrl, r->curStats, r->dSlow, countIdx);
+                               r->dHit, r->dCtrl, r->curStats, r->dSlow, countIdx);
         else
             hipLaunchKernelGGL((k_trace_slow<false>), dim3(r->numCUs), dim3(RTX_BLOCK), r->ldsSlow, r->stream, r->sc, o, d,
-                               r->dHitT, r->dHitLeaf, r->dCtrl, r->curStats, r->dSlow, countIdx);
+                               r->dHit, r->dCtrl, r->curStats, r->dSlow, countIdx);
         return;
     }
     if (r->mode == RTX_MODE_LINEAR) launch_trace<RTX_MODE_LINEAR>(r, o, d, countIdx, workIdx, fixedCount);
@@ -744,7 +744,7 @@ void rtx_destroy(RtxRenderer* r) {
     if (r->dPackedAtLeader && r->leaderDevice >= 0) { hipSetDevice(r->leaderDevice); hipFree(r->dPackedAtLeader); hipSetDevice(r->device); }
     for (auto& c : r->ctx) {
         if (c.stream) hipStreamSynchronize(c.stream);
-        void* own[] = {c.dRqO[0], c.dRqO[1], c.dRqD[0], c.dRqD[1], c.dHitT, c.dHitLeaf, c.dLight, c.dAcc, c.dSeeds, c.dCtrl, c.dSlow, c.dSpill};
+        void* own[] = {c.dRqO[0], c.dRqO[1], c.dRqD[0], c.dRqD[1], c.dHit, c.dLight, c.dAcc, c.dSeeds, c.dCtrl, c.dSlow, c.dSpill};
         for (void* p : own) if (p) hipFree(p);
         if (c.resolved) hipEventDestroy(c.resolved);
         if (c.countsReady) hipEventDestroy(c.countsReady);
@@ -990,8 +990,7 @@ static int build_renderer(const RtxSceneDesc* scene, const RtxConfig& cfg, const
             CREATE_HIP(hipMalloc((void**)&c.dRqO[k], nq * sizeof(float4)));
             CREATE_HIP(hipMalloc((void**)&c.dRqD[k], nq * sizeof(float4)));
         }
-        CREATE_HIP(hipMalloc((void**)&c.dHitT, nq * sizeof(float)));
-        CREATE_HIP(hipMalloc((void**)&c.dHitLeaf, nq * sizeof(int)));
+        CREATE_HIP(hipMalloc((void**)&c.dHit, nq * sizeof(int2)));
         CREATE_HIP(hipMalloc((void**)&c.dLight, n * sizeof(float4)));
         CREATE_HIP(hipMalloc((void**)&c.dAcc, n * sizeof(float4)));
         CREATE_HIP(hipMalloc((void**)&c.dSeeds, n * sizeof(uint32_t)));
@@ -1089,7 +1088,7 @@ static int render_batch(RtxRenderer* r, const std::pair<RtxCamera, uint32_t>* fr
                 HIP_TRY(hipEventRecord(ev[2 * b + 1], r->stream));
             }
             hipLaunchKernelGGL(k_shade, dim3(r->launchShade), dim3(RTX_BLOCK), 0, r->stream, r->sc, bt, r->dTiles, b, r->linear ? 1 : 0,
-                               r->dRqO[in], r->dRqD[in], r->dHitT, r->dHitLeaf, r->dRqO[in ^ 1], r->dRqD[in ^ 1],
+                               r->dRqO[in], r->dRqD[in], r->dHit, r->dRqO[in ^ 1], r->dRqD[in ^ 1],
                                r->dLight, r->dAcc, r->dSeeds, r->dCtrl, r->curStats, 2 * b + 1);
             HIP_TRY(hipEventRecord(ev[2 * b + 2], r->stream));
             in ^= 1;
@@ -1320,7 +1319,7 @@ static int primary_hits_one(RtxRenderer* r, const RtxCamera* camera, uint32_t fr
     hipError_t e = hipMemsetAsync(dIds, 0xff, npx * sizeof(int), r->stream);
     const DevFrame fr = make_frame(r, camera, frameCounter);
     if (e == hipSuccess && r->numSlots) {
-        hipLaunchKernelGGL(k_hits_to_ids, dim3((r->numSlots + 255) / 256), dim3(256), 0, r->stream, r->sc, fr, r->dTiles, r->dHitLeaf, dIds);
+        hipLaunchKernelGGL(k_hits_to_ids, dim3((r->numSlots + 255) / 256), dim3(256), 0, r->stream, r->sc, fr, r->dTiles, r->dHit, dIds);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpyAsync(objectIDs, dIds, npx * sizeof(int), hipMemcpyDeviceToHost, r->stream);
@@ -1337,7 +1336,7 @@ int rtx_trace_rays(RtxRenderer* r, const float* origins, const float* directions
     if (n > 0x7fffff00ull) return fail("too many rays");
     HIP_TRY(hipSetDevice(r->device));
     if (sync_all(r)) return 1;
-    float4 *dO = nullptr, *dD = nullptr, *dP = nullptr, *dN = nullptr; float* dT = nullptr; int *dL = nullptr, *dI = nullptr;
+    float4 *dO = nullptr, *dD = nullptr, *dP = nullptr, *dN = nullptr; int2* dH = nullptr; int* dI = nullptr;
     uint32_t* dSlowTmp = nullptr;
     // the 4th direction lane is a flag inside the queues (1 = no ray); callers' 4th lane is "ignored"
     std::vector<float> dirs(directions, directions + 4 * n);
@@ -1346,7 +1345,7 @@ int rtx_trace_rays(RtxRenderer* r, const float* origins, const float* directions
     auto ok = [&](hipError_t x) { if (e == hipSuccess) e = x; return e == hipSuccess; };
     ok(hipMalloc((void**)&dO, n * sizeof(float4))); ok(hipMalloc((void**)&dD, n * sizeof(float4)));
     ok(hipMalloc((void**)&dP, n * sizeof(float4))); ok(hipMalloc((void**)&dN, n * sizeof(float4)));
-    ok(hipMalloc((void**)&dT, n * sizeof(float))); ok(hipMalloc((void**)&dL, n * sizeof(int))); ok(hipMalloc((void**)&dI, n * sizeof(int)));
+    ok(hipMalloc((void**)&dH, n * sizeof(int2))); ok(hipMalloc((void**)&dI, n * sizeof(int)));
     ok(hipMalloc((void**)&dSlowTmp, n * sizeof(uint32_t)));
     if (e == hipSuccess) {
         ok(hipMemcpyAsync(dO, origins, n * sizeof(float4), hipMemcpyHostToDevice, r->stream));
@@ -1357,17 +1356,17 @@ int rtx_trace_rays(RtxRenderer* r, const float* origins, const float* directions
         ok(hipStreamSynchronize(r->stream));   // cnt is a stack variable
     }
     if (e == hipSuccess) {
-        float* saveT = r->dHitT; int* saveL = r->dHitLeaf; uint32_t* saveS = r->dSlow;
-        r->dHitT = dT; r->dHitLeaf = dL; r->dSlow = dSlowTmp;
+        int2* saveH = r->dHit; uint32_t* saveS = r->dSlow;
+        r->dHit = dH; r->dSlow = dSlowTmp;
         hipEvent_t t0 = nullptr, t1 = nullptr;
         ok(hipEventCreate(&t0)); ok(hipEventCreate(&t1));
         if (t0) ok(hipEventRecord(t0, r->stream));
         set_grids(r, (uint32_t)n);
         dispatch_trace(r, dO, dD, 1, 0, 0);
         if (t1) ok(hipEventRecord(t1, r->stream));
-        r->dHitT = saveT; r->dHitLeaf = saveL; r->dSlow = saveS;
+        r->dHit = saveH; r->dSlow = saveS;
         hipLaunchKernelGGL(k_probe_finish, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, r->stream, r->sc, r->linear ? 1 : 0,
-                           dO, dD, dT, dL, (uint32_t)n, dI, dP, dN);
+                           dO, dD, dH, (uint32_t)n, dI, dP, dN);
         ok(hipGetLastError());
         if (objectIDs) ok(hipMemcpyAsync(objectIDs, dI, n * sizeof(int), hipMemcpyDeviceToHost, r->stream));
         if (points) ok(hipMemcpyAsync(points, dP, n * sizeof(float4), hipMemcpyDeviceToHost, r->stream));
@@ -1378,7 +1377,7 @@ int rtx_trace_rays(RtxRenderer* r, const float* origins, const float* directions
         if (t0) hipEventDestroy(t0);
         if (t1) hipEventDestroy(t1);
     }
-    void* ptrs[] = {dO, dD, dP, dN, dT, dL, dI, dSlowTmp};
+    void* ptrs[] = {dO, dD, dP, dN, dH, dI, dSlowTmp};
     for (void* p : ptrs) if (p) hipFree(p);
     if (e != hipSuccess) return fail(std::string("rtx_trace_rays: ") + hipGetErrorString(e));
     return 0;
@@ -1398,21 +1397,20 @@ int rtx_trace_rays_noalloc(RtxRenderer* r, const float* d_origins, const float* 
     if (!base) return fail("rtx_trace_rays_noalloc: scratch address of this device is unknown");
     if (sync_all(r)) return 1;
     uint32_t* sCtrl = (uint32_t*)base;
-    float* sT = (float*)(base + RTX_NOALLOC_CTRL_BYTES);
-    int* sL = (int*)(sT + RTX_NOALLOC_MAX_RAYS);
-    uint32_t* sSlow = (uint32_t*)(sL + RTX_NOALLOC_MAX_RAYS);
+    int2* sH = (int2*)(base + RTX_NOALLOC_CTRL_BYTES);
+    uint32_t* sSlow = (uint32_t*)(sH + RTX_NOALLOC_MAX_RAYS);
     float4* sD = (float4*)(sSlow + RTX_NOALLOC_MAX_RAYS);
     const uint32_t cnt = (uint32_t)n;
     // the array keeps the last call's contents: the counters must start at zero, the queue length is this call's
     HIP_TRY(hipMemsetAsync(sCtrl, 0, RTX_CTRL_WORDS * sizeof(uint32_t), r->stream));
     hipLaunchKernelGGL(k_stage_directions, dim3((cnt + 255u) / 256u), dim3(256), 0, r->stream, (const float4*)d_directions, sD, cnt);
-    float* saveT = r->dHitT; int* saveL = r->dHitLeaf; uint32_t* saveS = r->dSlow; uint32_t* saveC = r->dCtrl;
-    r->dHitT = sT; r->dHitLeaf = sL; r->dSlow = sSlow; r->dCtrl = sCtrl;
+    int2* saveH = r->dHit; uint32_t* saveS = r->dSlow; uint32_t* saveC = r->dCtrl;
+    r->dHit = sH; r->dSlow = sSlow; r->dCtrl = sCtrl;
     set_grids(r, cnt);
     dispatch_trace(r, (const float4*)d_origins, sD, 0, 0, cnt);        // countIdx 0: the queue length travels as an argument
-    r->dHitT = saveT; r->dHitLeaf = saveL; r->dSlow = saveS; r->dCtrl = saveC;
+    r->dHit = saveH; r->dSlow = saveS; r->dCtrl = saveC;
     hipLaunchKernelGGL(k_probe_finish, dim3((cnt + 255u) / 256u), dim3(256), 0, r->stream, r->sc, r->linear ? 1 : 0,
-                       (const float4*)d_origins, sD, sT, sL, cnt, d_objectIDs, (float4*)d_points, (float4*)d_normals);
+                       (const float4*)d_origins, sD, sH, cnt, d_objectIDs, (float4*)d_points, (float4*)d_normals);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(r->stream));           // the next call on this GPU reuses the array
     return 0;

@@ -186,7 +186,7 @@ __device__ __forceinline__ void primary_ray(const DevFrame& fr, int x, int y, ui
 template <int MODE, bool COUNT>
 __global__ __launch_bounds__(RTX_BLOCK) RTX_PRIMARY_ATTR void k_primary(DevScene sc, DevBatch bt, const int2* __restrict__ tiles,
                                                        float4* __restrict__ rqO, float4* __restrict__ rqD,
-                                                       float* __restrict__ hitT, int* __restrict__ hitLeaf,
+                                                       int2* __restrict__ hit,
                                                        uint32_t* __restrict__ seeds, uint32_t* __restrict__ ctrl,
                                                        unsigned long long* __restrict__ stats, int workIdx) {
     int* stack = rtx_lds + threadIdx.x;
@@ -213,11 +213,10 @@ __global__ __launch_bounds__(RTX_BLOCK) RTX_PRIMARY_ATTR void k_primary(DevScene
             Hit h = closest_hit<MODE, COUNT>(sc, o.x, o.y, o.z, d.x, d.y, d.z, stack, ic, lc);
             rqO[slot] = make_float4(o.x, o.y, o.z, __int_as_float((int)slot));
             rqD[slot] = make_float4(d.x, d.y, d.z, 0.0f);
-            hitT[slot] = h.t;
-            hitLeaf[slot] = h.leaf;
+            hit[slot] = make_int2(__float_as_int(h.t), h.leaf);       // distance and leaf in one 8-byte store
             seeds[slot] = seed;
         } else {
-            hitLeaf[slot] = RTX_INVALID_SLOT;
+            hit[slot] = make_int2(0, RTX_INVALID_SLOT);
         }
     }
     if (COUNT) {
@@ -228,7 +227,7 @@ __global__ __launch_bounds__(RTX_BLOCK) RTX_PRIMARY_ATTR void k_primary(DevScene
 
 template <int MODE, bool COUNT>
 __global__ __launch_bounds__(RTX_BLOCK) void k_trace(DevScene sc, const float4* __restrict__ rqO, const float4* __restrict__ rqD,
-                                                     float* __restrict__ hitT, int* __restrict__ hitLeaf,
+                                                     int2* __restrict__ hit,
                                                      uint32_t* __restrict__ ctrl, unsigned long long* __restrict__ stats,
                                                      uint32_t fixedCount, int countIdx, int workIdx) {
     int* stack = rtx_lds + threadIdx.x;
@@ -242,11 +241,10 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_trace(DevScene sc, const float4* 
         if (q < count) {
             float4 o = rqO[q], d = rqD[q];
             if (d.w != 0.0f) {
-                hitLeaf[q] = RTX_INVALID_SLOT;      // hole left by k_shade's run reservation
+                hit[q] = make_int2(0, RTX_INVALID_SLOT);      // hole left by k_shade's run reservation
             } else {
                 Hit h = closest_hit<MODE, COUNT>(sc, o.x, o.y, o.z, d.x, d.y, d.z, stack, ic, lc);
-                hitT[q] = h.t;
-                hitLeaf[q] = h.leaf;
+                hit[q] = make_int2(__float_as_int(h.t), h.leaf);
             }
         }
     }
@@ -280,7 +278,7 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_trace(DevScene sc, const float4* 
 // the three bounces — whose durations differ by 4x — under three kernel names.
 template <bool COUNT, int BOUNCE, bool BIG>
 __global__ __launch_bounds__(RTX_BLOCK) void k_trace_refill(DevScene sc, const float4* __restrict__ rqO, const float4* __restrict__ rqD,
-                                                            float* __restrict__ hitT, int* __restrict__ hitLeaf,
+                                                            int2* __restrict__ hit,
                                                             uint32_t* __restrict__ ctrl, unsigned long long* __restrict__ stats,
                                                             uint32_t* __restrict__ slowList, uint32_t fixedCount, int workIdx) {
     const int countIdx = BOUNCE;
@@ -338,7 +336,7 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_trace_refill(DevScene sc, const f
                     const float4 o = rqO[q], d = rqD[q];
                     dx = d.x; dy = d.y; dz = d.z;
                     if (d.w != 0.0f) {
-                        hitLeaf[q] = RTX_INVALID_SLOT;     // slot outside the image, or a hole in a bounce queue
+                        hit[q] = make_int2(0, RTX_INVALID_SLOT);     // slot outside the image, or a hole in a bounce queue
                     } else if (lane_is_clean(o.x, o.y, o.z, dx, dy, dz)) {
                         w = wide_ray(o.x, o.y, o.z, 1.0f / dx, 1.0f / dy, 1.0f / dz);
                         best.t = INFINITY; best.leaf = -1; best.box = -1; limit = INFINITY;
@@ -384,7 +382,7 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_trace_refill(DevScene sc, const f
                         if (!(tn > limit)) { cur = ref; finished = false; break; }
                     }
                     if (finished) {
-                        hitT[q] = best.t; hitLeaf[q] = best.leaf;
+                        hit[q] = make_int2(__float_as_int(best.t), best.leaf);
                         cur = RTX_IDLE;
                     }
                 }
@@ -410,7 +408,7 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_trace_refill(DevScene sc, const f
 #endif
 template <bool COUNT, int BOUNCE, bool BIG>
 __global__ __launch_bounds__(RTX_BLOCK) RTX_TRACEQ_ATTR void k_trace_q(DevScene sc, const float4* __restrict__ rqO, const float4* __restrict__ rqD,
-                                                       float* __restrict__ hitT, int* __restrict__ hitLeaf,
+                                                       int2* __restrict__ hit,
                                                        uint32_t* __restrict__ ctrl, unsigned long long* __restrict__ stats,
                                                        uint32_t* __restrict__ slowList, uint32_t fixedCount, int workIdx) {
     const int countIdx = BOUNCE;
@@ -477,7 +475,7 @@ __global__ __launch_bounds__(RTX_BLOCK) RTX_TRACEQ_ATTR void k_trace_q(DevScene 
                 st.nsp = start ? 0 : st.nsp; st.nbase = start ? 0 : st.nbase; st.lsp = start ? 0 : st.lsp;
                 nodeCur = start ? RTX_QENTRY(0, 1) : nodeCur; leafCur = start ? 0 : leafCur;
                 busy = busy || start;
-                if (mine && hole) hitLeaf[qn] = RTX_INVALID_SLOT;
+                if (mine && hole) hit[qn] = make_int2(0, RTX_INVALID_SLOT);
                 // axis-parallel / non-finite ray: k_trace_slow walks the reference topology for it
                 if (mine && !hole && !clean) slowList[atomicAdd(&ctrl[RTX_CTRL_SLOW(countIdx)], 1u)] = qn;
                 rcur += take;
@@ -489,7 +487,7 @@ __global__ __launch_bounds__(RTX_BLOCK) RTX_TRACEQ_ATTR void k_trace_q(DevScene 
             if (COUNT) wp++;
             if (busy) {
                 if (!q_pass<COUNT, BIG>(nodes, leaves, r, dx, dy, dz, nodeCur, leafCur, st, best, ic, lc)) {
-                    hitT[q] = best.t; hitLeaf[q] = best.leaf;
+                    hit[q] = make_int2(__float_as_int(best.t), best.leaf);
                     busy = false;
                 }
             }
@@ -509,7 +507,7 @@ __global__ __launch_bounds__(RTX_BLOCK) RTX_TRACEQ_ATTR void k_trace_q(DevScene 
 // reference's topology and the reference's exact semantics. Full-depth stack in LDS (small grid).
 template <bool COUNT>
 __global__ __launch_bounds__(RTX_BLOCK) void k_trace_slow(DevScene sc, const float4* __restrict__ rqO, const float4* __restrict__ rqD,
-                                                          float* __restrict__ hitT, int* __restrict__ hitLeaf,
+                                                          int2* __restrict__ hit,
                                                           const uint32_t* __restrict__ ctrl, unsigned long long* __restrict__ stats,
                                                           const uint32_t* __restrict__ slowList, int countIdx) {
     int* stack = rtx_lds + threadIdx.x;
@@ -519,7 +517,7 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_trace_slow(DevScene sc, const flo
         const uint32_t q = slowList[i];
         const float4 o = rqO[q], d = rqD[q];
         Hit h = traverse_bvh<true, COUNT>(sc, o.x, o.y, o.z, d.x, d.y, d.z, stack, RTX_BLOCK, ic, lc);
-        hitT[q] = h.t; hitLeaf[q] = h.leaf;
+        hit[q] = make_int2(__float_as_int(h.t), h.leaf);
     }
     if (COUNT) {
         ic = wave_sum(ic); lc = wave_sum(lc);
@@ -530,7 +528,7 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_trace_slow(DevScene sc, const flo
 // src/ThreadedShader.cpp:155-180 for bounce `bounce` of every queued path.
 __global__ __launch_bounds__(RTX_BLOCK) void k_shade(DevScene sc, DevBatch bt, const int2* __restrict__ tiles, int bounce, int linearMode,
                                                      const float4* __restrict__ rqOin, const float4* __restrict__ rqDin,
-                                                     const float* __restrict__ hitT, const int* __restrict__ hitLeaf,
+                                                     const int2* __restrict__ hit,
                                                      float4* __restrict__ rqOout, float4* __restrict__ rqDout,
                                                      float4* __restrict__ lightArr, float4* __restrict__ accArr,
                                                      uint32_t* __restrict__ seeds,
@@ -551,8 +549,8 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_shade(DevScene sc, DevBatch bt, c
         if (base == 0xffffffffu) break;
         const uint32_t q = base + lane;
         bool active = q < count;
-        int leaf = -1;
-        if (active) { leaf = hitLeaf[q]; active = leaf != RTX_INVALID_SLOT; }
+        int leaf = -1; float hitDistance = 0.0f;
+        if (active) { const int2 h = hit[q]; leaf = h.y; hitDistance = __int_as_float(h.x); active = leaf != RTX_INVALID_SLOT; }
         bool alive = false;
         F4 o = mk4(0, 0, 0), d = mk4(0, 0, 0), light = mk4(1, 1, 1, 1), acc = mk4(0, 0, 0, 0);
         uint32_t seed = 0; int slot = 0;
@@ -570,7 +568,7 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_shade(DevScene sc, DevBatch bt, c
                 hits++;
                 seed = seeds[slot];
                 HitPrim prim = load_prim(sc, leaf);
-                float t = hitT[q];
+                float t = hitDistance;
                 F4 dirForPoint = linearMode ? mul4(d, 1.0000001f) : d;   // src/ThreadedShader.cpp:217,232
                 F4 point = add4(o, mul4(dirForPoint, t));
                 F4 normal = hit_normal(prim, point);
@@ -643,23 +641,24 @@ __global__ void k_add_stats(unsigned long long* __restrict__ dst, const unsigned
 }
 
 // ---- probes -------------------------------------------------------------------
-__global__ void k_hits_to_ids(DevScene sc, DevFrame fr, const int2* __restrict__ tiles, const int* __restrict__ hitLeaf, int* __restrict__ ids) {
+__global__ void k_hits_to_ids(DevScene sc, DevFrame fr, const int2* __restrict__ tiles, const int2* __restrict__ hit, int* __restrict__ ids) {
     uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
     if (slot >= (uint32_t)fr.numSlots) return;
     int x, y;
     if (!slot_to_pixel(fr, tiles, slot, x, y)) return;
-    int leaf = hitLeaf[slot];
+    int leaf = hit[slot].y;
     int id = -1;
     if (leaf >= 0) id = __float_as_int(sc.shade[(size_t)leaf * 8 + 2].y);
     ids[(size_t)y * fr.width + x] = id;
 }
 
 __global__ void k_probe_finish(DevScene sc, int linearMode, const float4* __restrict__ rqO, const float4* __restrict__ rqD,
-                               const float* __restrict__ hitT, const int* __restrict__ hitLeaf, uint32_t n,
+                               const int2* __restrict__ hit, uint32_t n,
                                int* __restrict__ ids, float4* __restrict__ points, float4* __restrict__ normals) {
     uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= n) return;
-    int leaf = hitLeaf[q];
+    const int2 h = hit[q];
+    int leaf = h.y;
     int id = -1; F4 point = mk4(0, 0, 0), normal = mk4(0, 0, 0);
     if (leaf >= 0) {
         HitPrim prim = load_prim(sc, leaf);
@@ -667,7 +666,7 @@ __global__ void k_probe_finish(DevScene sc, int linearMode, const float4* __rest
         float4 o4 = rqO[q], d4 = rqD[q];
         F4 o = mk4(o4.x, o4.y, o4.z), d = mk4(d4.x, d4.y, d4.z);
         F4 dirForPoint = linearMode ? mul4(d, 1.0000001f) : d;
-        point = add4(o, mul4(dirForPoint, hitT[q]));
+        point = add4(o, mul4(dirForPoint, __int_as_float(h.x)));
         normal = hit_normal(prim, point);
     }
     if (ids) ids[q] = id;
