@@ -286,7 +286,7 @@ def main():
                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                     "traffic": traffic, "traffic_source": traffic_source,
                     "hbm_traffic_gbs": (traffic / (trace_ms[b] * 1e-3) / 1e9) if (traffic and trace_ms[b] > 0) else None,
-                    "limiter": "not HBM: dependent-load latency at the occupancy the kernel reaches, then VALU issue (DESIGN.md section 6); "
+                    "limiter": "not HBM: VALU issue (busy 1.06) and the vector L1's access rate (0.79 of 0.87 per clock per CU), both at their ceilings at once (DESIGN.md section 6); "
                                "`achieved` prices device-counted visits at SURVEY 8d's 64 B / 48 B, most of which the L2 / Infinity Cache serve",
                     "algorithmic_bytes_per_launch": algo_bytes, "launch_ms": trace_ms[b],
                     "launch_ms_overlapped_in_timed_region": [kernel_ms[0], kernel_ms[2], kernel_ms[4], kernel_ms[6]][b],

@@ -855,7 +855,7 @@ static int build_renderer(const RtxSceneDesc* scene, const RtxConfig& cfg, const
                                              : (flat.qnodes.empty() ? RTX_MODE_CULLED : RTX_MODE_WIDEQ));
     const size_t bigNodes = (size_t)1 << 25;      // 128-byte nodes / 64-byte nodes: 4 GiB of either
     if (r->mode == RTX_MODE_CULLED && (flat.fast.size() > bigNodes || getenv("RTX_FORCE_BIG"))) r->mode = RTX_MODE_CULLED_BIG;
-    if (r->mode == RTX_MODE_WIDEQ && (flat.qnodes.size() > 2 * bigNodes || getenv("RTX_FORCE_BIG"))) r->mode = RTX_MODE_WIDEQ_BIG;
+    if (r->mode == RTX_MODE_WIDEQ && (flat.qnodes.size() * sizeof(rtxbuild::NodeQ) > ((size_t)4 << 30) || getenv("RTX_FORCE_BIG"))) r->mode = RTX_MODE_WIDEQ_BIG;
     const bool quant = r->mode == RTX_MODE_WIDEQ || r->mode == RTX_MODE_WIDEQ_BIG;
     const bool culled = r->mode == RTX_MODE_CULLED || r->mode == RTX_MODE_CULLED_BIG || quant;      // any walk of the own tree
     r->tileW = cfg.tileW; r->tileH = cfg.tileH;

@@ -650,10 +650,13 @@ inline void single_leaf_node4(const Box* leafBox, Raw<Node4>& out) {
 // its leaf children are neighbours in the leaf array, so the node stores two bases instead of four refs:
 // child in slot j = node baseInner + j, or leaf baseLeaf + j (bases are pre-biased; slots are what the valid /
 // leaf masks and the byte lanes are indexed by).
-struct NodeQ {          // 64-byte slot, 48 bytes used
+#ifndef RTX_QNODE_WORDS
+#define RTX_QNODE_WORDS 16      // words from one node to the next: 16 = one node per 64-byte slot, 12 = packed
+#endif
+struct NodeQ {          // 48 bytes used
     // w[0..2] origin.xyz  w[3] = ex | ey << 8 | ez << 16 | valid << 24 | leaf << 28   (e* = biased float exponent of the step)
     // w[4] lo.x bytes (slot j in byte j)  w[5] hi.x  w[6] lo.y  w[7] hi.y  w[8] lo.z  w[9] hi.z  w[10] baseInner  w[11] baseLeaf
-    uint32_t w[16];
+    uint32_t w[RTX_QNODE_WORDS];
 };
 
 // Converts the Node4 tree (root = node 0) into NodeQ records (root = node 0 again) and returns, for every new leaf
@@ -727,7 +730,7 @@ inline bool quantize4(const Raw<Node4>& in, Raw<NodeQ>& out, std::vector<uint32_
             const Plan& p = plan[i];
             const float* q = in[i].q;
             NodeQ& o = out[(size_t)p.newIdx];
-            o.w[12] = o.w[13] = o.w[14] = o.w[15] = 0;
+            for (int k = 12; k < RTX_QNODE_WORDS; ++k) o.w[k] = 0;
             const int nc = p.ni + p.nl;
             uint32_t meta = 0;
             for (int a = 0; a < 3; ++a) {

@@ -424,17 +424,20 @@ struct QStack {
 
 #define RTX_QENTRY(base, mask) ((int)(((uint32_t)(base) << 4) | (mask)))
 
+#ifndef RTX_QNODE_WORDS
+#define RTX_QNODE_WORDS 16      // rtx_build.h NodeQ
+#endif
 // The three lane loads of a node step. BIG: node arrays beyond 4 GiB (2^26 nodes) take 64-bit lane addresses.
 struct QNodeData { uint4 a, b, c; };
 template <bool BIG>
 __device__ __forceinline__ QNodeData q_load_node(const uint4* __restrict__ nodes, int idx) {
     QNodeData n;
     if (BIG) {
-        const uint4* N = nodes + (size_t)(uint32_t)idx * 4;
+        const uint4* N = (const uint4*)((const char*)nodes + (size_t)(uint32_t)idx * (RTX_QNODE_WORDS * 4));
         n.a = N[0]; n.b = N[1]; n.c = N[2];
     } else {
         const char* base = (const char*)nodes;
-        const uint32_t off = (uint32_t)idx << 6;
+        const uint32_t off = (uint32_t)idx * (uint32_t)(RTX_QNODE_WORDS * 4);
         n.a = *(const uint4*)(base + off); n.b = *(const uint4*)(base + off + 16); n.c = *(const uint4*)(base + off + 32);
     }
     return n;
