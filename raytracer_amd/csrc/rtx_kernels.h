@@ -525,8 +525,13 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_trace_slow(DevScene sc, const flo
     }
 }
 
+#if defined(RTX_SHADE_WAVES)
+#define RTX_SHADE_ATTR __attribute__((amdgpu_waves_per_eu(RTX_SHADE_WAVES, RTX_SHADE_WAVES)))
+#else
+#define RTX_SHADE_ATTR
+#endif
 // src/ThreadedShader.cpp:155-180 for bounce `bounce` of every queued path.
-__global__ __launch_bounds__(RTX_BLOCK) void k_shade(DevScene sc, DevBatch bt, const int2* __restrict__ tiles, int bounce, int linearMode,
+__global__ __launch_bounds__(RTX_BLOCK) RTX_SHADE_ATTR void k_shade(DevScene sc, DevBatch bt, const int2* __restrict__ tiles, int bounce, int linearMode,
                                                      const float4* __restrict__ rqOin, const float4* __restrict__ rqDin,
                                                      const int2* __restrict__ hit,
                                                      float4* __restrict__ rqOout, float4* __restrict__ rqDout,
