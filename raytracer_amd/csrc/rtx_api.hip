@@ -139,16 +139,19 @@ struct RtxRenderer {
     std::vector<hipEvent_t> stageEv;
     hipStream_t copyStream = nullptr;   // frame delivery, so that it waits for the frame's resolve only
 
-    // Look-ahead for the synchronous pattern (the reference's loop: Render(pixels); frameCounter++, src/WindowManager.cpp:154-158).
+    // Look-ahead for the synchronous pattern (the reference's loop: Render(pixels); frameCounter++, src/WindowManager.cpp:154-158;
+    // or rtx_render(NULL) + rtx_present_rgba8 / rtx_download_pixels per frame).
     // A call that has to hand the frame back cannot overlap with the next one — unless the next one is started before it
-    // is asked for. When two calls in a row asked for (camera, n) and (camera, n + 1), frames n + 2 (and n + 3) are queued on
-    // the next contexts before frame n + 1 is copied out: everything but their resolve, with work counters of their own.
-    // The next call either asks for exactly the oldest of them (its resolve is queued, its counters are added, and the
-    // look-ahead is topped up) or for something else (they are dropped: their launches run out unused, nothing they
-    // wrote is ever read).
+    // is asked for. When two frames in a row were (camera, n) and (camera, n + 1), each delivered before the next was asked
+    // for, frames n + 2 (and n + 3) are queued on the next contexts before frame n + 1 is copied out: everything but their
+    // resolve, with work counters of their own. The next rtx_render either asks for exactly the oldest of them (its resolve
+    // is queued, its counters are added, and the look-ahead is topped up at the next delivery) or for something else (they
+    // are dropped: their launches run out unused, nothing they wrote is ever read). Every other entry point drops them too.
     struct Ahead { RtxCamera cam{}; uint32_t fc = 0; int ctx = -1; DevBatch bt{}; };
     std::deque<Ahead> ahead;            // frames started ahead, oldest first: consecutive frame counters, one camera
-    bool haveLastSync = false; RtxCamera lastSyncCam{}; uint32_t lastSyncFc = 0; int syncStreak = 0;
+    bool haveLast = false; RtxCamera lastCam{}; uint32_t lastFc = 0;      // the last frame asked for
+    int streak = 0;                     // calls in a row that asked for (same camera, frame counter + 1)
+    int rendersSinceDelivery = 0;       // the loop is: one frame, one delivery
     int lookAhead = 0;                  // how many frames are started ahead (0: never)
 };
 
@@ -1131,8 +1134,6 @@ static int take_ahead(RtxRenderer* r) {
 
 // renders whatever rtx_render(pixels = NULL) has collected
 static int flush_queued(RtxRenderer* r) {
-    // whatever comes next is not the frame that was started ahead (render_one checks for that before it gets here)
-    r->ahead.clear(); r->haveLastSync = false; r->syncStreak = 0;
     if (r->queued.empty()) return 0;
     std::vector<std::pair<RtxCamera, uint32_t>> q;
     q.swap(r->queued);
@@ -1140,7 +1141,11 @@ static int flush_queued(RtxRenderer* r) {
 }
 
 // every frame queued or in flight finished (the host-side entry points that touch the framebuffer start here)
+// frames started ahead are not going to be asked for (and the loop, if there was one, is over)
+static void drop_ahead(RtxRenderer* r) { r->ahead.clear(); r->haveLast = false; r->streak = 0; r->rendersSinceDelivery = 0; }
+
 static int sync_all(RtxRenderer* r) {
+    drop_ahead(r);
     if (flush_queued(r)) return 1;
     for (auto& c : r->ctx) if (c.stream) HIP_TRY(hipStreamSynchronize(c.stream));
     return 0;
@@ -1240,6 +1245,35 @@ static int gather_group(RtxRenderer* r) {
     return 0;
 }
 
+static bool delivers_with_look_ahead(const RtxRenderer* r) {
+    return r->lookAhead > 0 && r->batch == 1 && r->peers.empty() && !r->leader && r->copyStream && !getenv("RTX_PLAIN_COPY");
+}
+
+// Hands the image back: the float frame, or (present) its 8-bit conversion. Waits for the resolve that was queued last —
+// the resolves are chained, so every frame asked for so far is in — and not for frames started ahead; tops the look-ahead
+// up before the copy when the caller is in the loop "one frame, one delivery".
+static int deliver(RtxRenderer* r, bool present, float gamma, void* dst) {
+    HIP_TRY(hipSetDevice(r->device));
+    if (r->lastResolved >= 0) HIP_TRY(hipStreamWaitEvent(r->copyStream, r->ctx[r->lastResolved].resolved, 0));
+    const uint32_t n = r->width * r->height;
+    const char* src = (const char*)r->dFb;
+    size_t bytes = (size_t)n * sizeof(float4);
+    if (present) {
+        if (!r->dPresent) HIP_TRY(hipMalloc((void**)&r->dPresent, (size_t)n * sizeof(uint32_t)));
+        hipLaunchKernelGGL(k_present_rgba8, dim3((n + 255u) / 256u), dim3(256), 0, r->copyStream, r->dFb, r->dPresent, n, gamma > 0.0f ? 1.0f / gamma : 0.0f);
+        HIP_TRY(hipGetLastError());
+        src = (const char*)r->dPresent; bytes = (size_t)n * sizeof(uint32_t);
+    }
+    const bool loop = r->rendersSinceDelivery == 1 && r->streak >= 1 && r->haveLast;
+    r->rendersSinceDelivery = 0;
+    while (loop && (int)r->ahead.size() < r->lookAhead) {
+        const std::pair<RtxCamera, uint32_t> next(r->lastCam, r->lastFc + 1u + (uint32_t)r->ahead.size());
+        if (render_batch(r, &next, 1, false, true)) return 1;
+    }
+    if (stage_queue(r, r->copyStream, src, bytes)) return 1;
+    return stage_deliver(r, (char*)dst, bytes);
+}
+
 static int render_one(RtxRenderer* r, const RtxCamera* camera, uint32_t frameCounter, float* pixels_rgba);
 
 int rtx_render(RtxRenderer* r, const RtxCamera* camera, uint32_t frameCounter, float* pixels_rgba) {
@@ -1263,26 +1297,18 @@ static int render_one(RtxRenderer* r, const RtxCamera* camera, uint32_t frameCou
         if ((int)r->queued.size() >= r->batch) return flush_queued(r);
         return 0;
     }
-    const size_t fbBytes = (size_t)r->width * r->height * sizeof(float4);
-    if (pixels_rgba && r->lookAhead > 0 && r->batch == 1 && !getenv("RTX_PLAIN_COPY")) {
-        // the synchronous pattern, with look-ahead (RtxRenderer::Ahead)
-        const bool predicted = r->haveLastSync && frameCounter == r->lastSyncFc + 1u && memcmp(camera, &r->lastSyncCam, sizeof(RtxCamera)) == 0;
-        const int streak = predicted ? r->syncStreak + 1 : 0;
+    if (delivers_with_look_ahead(r)) {
+        const bool predicted = r->haveLast && frameCounter == r->lastFc + 1u && memcmp(camera, &r->lastCam, sizeof(RtxCamera)) == 0;
+        r->streak = predicted ? r->streak + 1 : 0;
         if (!r->ahead.empty() && r->ahead.front().fc == frameCounter && memcmp(camera, &r->ahead.front().cam, sizeof(RtxCamera)) == 0) {
             if (take_ahead(r)) return 1;
         } else {
-            if (render_frame(r, camera, frameCounter, false)) return 1;      // drops a look-ahead frame that was not asked for
+            r->ahead.clear();                      // started for nothing
+            if (render_frame(r, camera, frameCounter, false)) return 1;
         }
-        r->haveLastSync = true; r->lastSyncCam = *camera; r->lastSyncFc = frameCounter; r->syncStreak = streak;
-        const int mine = r->active;
-        while (streak >= 1 && (int)r->ahead.size() < r->lookAhead) {
-            const std::pair<RtxCamera, uint32_t> next(*camera, frameCounter + 1u + (uint32_t)r->ahead.size());
-            if (render_batch(r, &next, 1, false, true)) return 1;
-        }
-        // delivery waits for this frame's resolve, not for what was started after it
-        HIP_TRY(hipStreamWaitEvent(r->copyStream, r->ctx[mine].resolved, 0));
-        if (stage_queue(r, r->copyStream, (const char*)r->dFb, fbBytes)) return 1;
-        return stage_deliver(r, (char*)pixels_rgba, fbBytes);
+        r->haveLast = true; r->lastCam = *camera; r->lastFc = frameCounter; r->rendersSinceDelivery++;
+        if (!pixels_rgba) return 0;
+        return deliver(r, false, 0.0f, pixels_rgba);
     }
     if (render_frame(r, camera, frameCounter, false)) return 1;
     if (pixels_rgba) return copy_out(r, pixels_rgba);
@@ -1312,6 +1338,7 @@ int rtx_primary_hits(RtxRenderer* r, const RtxCamera* camera, uint32_t frameCoun
 }
 
 static int primary_hits_one(RtxRenderer* r, const RtxCamera* camera, uint32_t frameCounter, int32_t* objectIDs) {
+    drop_ahead(r);
     if (render_frame(r, camera, frameCounter, true)) return 1;
     const size_t npx = (size_t)r->width * r->height;
     int* dIds = nullptr;
@@ -1427,6 +1454,10 @@ int rtx_upload_pixels(RtxRenderer* r, const float* pixels) {
 }
 int rtx_download_pixels(RtxRenderer* r, float* pixels) {
     if (!r || !pixels) return fail("NULL argument");
+    if (delivers_with_look_ahead(r)) {
+        if (flush_queued(r)) return 1;
+        return deliver(r, false, 0.0f, pixels);
+    }
     if (gather_group(r)) return 1;
     HIP_TRY(hipSetDevice(r->device));
     if (sync_all(r)) return 1;
@@ -1436,6 +1467,10 @@ int rtx_download_pixels(RtxRenderer* r, float* pixels) {
 int rtx_present_rgba8(RtxRenderer* r, float gamma, uint8_t* rgba8) {
     if (!r || !rgba8) return fail("NULL argument");
     if (r->leader) return fail("this renderer is a member of a device group: call its leader");
+    if (delivers_with_look_ahead(r)) {
+        if (flush_queued(r)) return 1;
+        return deliver(r, true, gamma, rgba8);
+    }
     if (gather_group(r)) return 1;
     HIP_TRY(hipSetDevice(r->device));
     if (sync_all(r)) return 1;

@@ -399,6 +399,8 @@ def test_look_ahead_of_the_synchronous_loop_is_invisible(scene2, monkeypatch):
               ("r", (cam2, 11)), ("r", (cam2, 12)), ("upload", start), ("r", (cam2, 13)),    # the accumulator is replaced while frames are ahead
               ("r", (cam2, 14)), ("q", (cam2, 15)), ("q", (cam2, 16)), ("r", (cam2, 17)),    # queued frames in between
               ("r", (cam2, 18)), ("ids", (cam, 3)), ("r", (cam2, 19)), ("r", (cam2, 20)),
+              ("p", (cam2, 21)), ("p", (cam2, 22)), ("p", (cam2, 23)), ("p", (cam2, 24)), ("d", (cam2, 25)), ("d", (cam2, 26)),   # the loop with present / download as the delivery
+              ("d", (cam2, 27)), ("p", (cam, 28)), ("r", (cam, 29)), ("d", (cam, 30)), ("q", (cam, 31)), ("p", (cam, 32)),
               ("clear", None), ("r", (cam, 0)), ("r", (cam, 1)), ("r", (cam, 2)), ("counters", None), ("r", (cam, 3))]
     runs = {}
     for ahead in ("0", "2"):
@@ -407,10 +409,12 @@ def test_look_ahead_of_the_synchronous_loop_is_invisible(scene2, monkeypatch):
         px = np.zeros((d.height, d.width, 4), np.float32)
         log = []
         for op, arg in script:
-            if op in ("r", "q"):
+            if op in ("r", "q", "p", "d"):
                 r.frame_counter = arg[1]
                 r.Render(px if op == "r" else None, arg[0])
                 if op == "r": log.append(px.copy())
+                if op == "p": log.append(r.present(2.2).view(np.uint32).copy())
+                if op == "d": log.append(r.download())
             elif op == "upload": r.upload(arg)
             elif op == "clear": r.clear()
             elif op == "ids": log.append(r.primary_hits(arg[1], arg[0]).copy())
@@ -423,7 +427,7 @@ def test_look_ahead_of_the_synchronous_loop_is_invisible(scene2, monkeypatch):
     assert len(runs["0"]) == len(runs["2"])
     for a, b in zip(runs["0"], runs["2"]):
         assert a.dtype == b.dtype and (a.view(np.uint32) == b.view(np.uint32)).all()
-    frames = sum(1 for op, _ in script if op in ("r", "q"))
+    frames = sum(1 for op, _ in script if op in ("r", "q", "p", "d"))
     assert runs["2"][-1][0] == frames and runs["2"][-1][1] == frames * d.width * d.height      # frames dropped unused are not counted
     # and the oracle's image for the last stretch (after the clear)
     want = np.zeros((d.height, d.width, 4), np.float32)
