@@ -230,13 +230,13 @@ def main():
     # ---- roofline of the dominant kernel (rank 0) ---------------------------------------------------------
     # The timed region keeps several frames in flight, so a launch there shares the machine with launches of
     # other frames and its duration is not its own. The roofline pass renders the same frames again one at a
-    # time (framesInFlight = 1) with the counting instantiation of the kernels: node steps, leaf tests and the
+    # time (framesInFlight = 1, framesPerBatch = 1) with the counting instantiation of the kernels: node steps, leaf tests and the
     # HIP-event duration then come from the very same launches (the counters cost ~3 %).
     roofline = None
     if rank == 0:
         shader.close()
         counter = HIPShader(scene, device=local_rank, rank=rank, world_size=world, traversal=trav, count_stats=True,
-                            frames_in_flight=1)
+                            frames_in_flight=1, frames_per_batch=1 if world == 1 else 0)
         step(counter, 0)
         counter.reset_counters()
         for i in range(args.steps):
@@ -308,7 +308,7 @@ def main():
         # the same rays, and the bandwidth they would amount to in this kernel's time ("work-equivalent")
         if args.traversal != "exact" and not args.no_extras:
             refc = HIPShader(scene, device=local_rank, rank=rank, world_size=world, traversal=_capi.TRAVERSE_EXACT, count_stats=True,
-                             frames_in_flight=1)
+                             frames_in_flight=1, frames_per_batch=1 if world == 1 else 0)
             step(refc, args.warmup)
             rc = refc.counters()
             refc.close()

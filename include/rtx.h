@@ -147,8 +147,9 @@ typedef struct RtxConfig {
                               mean is still updated in frame order); 1 = strictly serial; 0 -> as many as the
                               process has hardware queues for: 3 with HIP's default GPU_MAX_HW_QUEUES=4,
                               6 with GPU_MAX_HW_QUEUES=8, 14 with 16 (an environment variable HIP reads at
-                              start-up); at most 16. Each frame in flight holds its own ray queues and path
-                              state: about 125 B per pixel of this rank's tiles */
+                              start-up), but no more than 3 batches when frames are rendered 8 at a time
+                              (framesPerBatch); at most 16. Each batch in flight holds its own ray queues and path
+                              state: about 125 B per pixel of this rank's tiles and frame of the batch */
     int32_t numDevices;    /* > 1: a DEVICE GROUP in this one process — devices[0..numDevices) each render the tiles   */
     int32_t devices[8];    /* of rank i of numDevices (scene flattened once, replicated), and every call that delivers
                               a frame (rtx_render with pixels, rtx_download_pixels) first gathers the members' tiles
@@ -164,6 +165,12 @@ typedef struct RtxConfig {
                               first of them or they are dropped unused. Results and counters are the same either way;
                               a wrong guess costs device time only. 0 -> up to 3, at most framesInFlight - 1 (2 with
                               HIP's default 4 hardware queues); -1 -> never. */
+    int32_t framesPerBatch;/* frames queued with pixels_rgba == NULL are collected and rendered `framesPerBatch` at a time by
+                              one set of launches (longer queues: the thin ends of the launches are shared by the frames of a
+                              batch); any call that needs results renders what has been collected first, so results do not
+                              depend on it. 0 -> 8 on a single rank (ranks of a process group: as many as make the rank's queues
+                              a whole frame long), at most 8; 1 -> every frame is launched by the call that queues it.
+                              Each frame of a batch in flight holds about 125 B per pixel of this rank's tiles. */
 } RtxConfig;
 
 typedef struct RtxCounters {

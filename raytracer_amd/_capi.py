@@ -36,7 +36,7 @@ class Config(C.Structure):
     _fields_ = [("device", C.c_int32), ("rank", C.c_int32), ("worldSize", C.c_int32),
                 ("tileW", C.c_int32), ("tileH", C.c_int32), ("traversal", C.c_int32),
                 ("countStats", C.c_int32), ("framesInFlight", C.c_int32),
-                ("numDevices", C.c_int32), ("devices", C.c_int32 * 8), ("lookAhead", C.c_int32)]
+                ("numDevices", C.c_int32), ("devices", C.c_int32 * 8), ("lookAhead", C.c_int32), ("framesPerBatch", C.c_int32)]
 
 
 class Counters(C.Structure):

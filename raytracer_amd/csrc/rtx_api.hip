@@ -103,6 +103,7 @@ struct RtxRenderer {
         uint32_t* hCounts = nullptr;       // pinned: the frame's queue lengths, copied back without a sync
         hipEvent_t countsReady = nullptr;
         bool countsPending = false;
+        int countsFrames = 1;              // how many frames those counts belong to
         unsigned long long* dStatsAhead = nullptr;   // work counters of a look-ahead frame, added to dStats when the frame is asked for
     };
     std::vector<FrameCtx> ctx;
@@ -949,10 +950,13 @@ static int build_renderer(const RtxSceneDesc* scene, const RtxConfig& cfg, const
 
     // per-path state (indexed by slot) and queues (indexed by queue position; the bounce queues hold
     // up to one unfinished run of holes per shade wave on top of the live rays)
-    // frames per batch: as many as make this rank's queues about as long as a whole frame's (1 on a single rank)
+    // frames per batch: on a rank of a process group as many as make the rank's queues about as long as a whole frame's;
+    // on a single rank 8 (measured at 4K / 10 M triangles, queued frames: 6.58 ms per frame one at a time with 14 in
+    // flight, 6.27 / 6.06 / 5.95 ms in batches of 2 / 4 / 8 — the launches' thin ends are shared by the frames of a batch)
     {
         const uint64_t allSlots = (uint64_t)r->tilesX * r->tilesY * r->tileW * r->tileH;
-        uint64_t want = r->numSlots ? allSlots / r->numSlots : 1;
+        uint64_t want = cfg.worldSize > 1 ? (r->numSlots ? allSlots / r->numSlots : 1) : RTX_MAX_BATCH;
+        if (cfg.framesPerBatch > 0) want = (uint64_t)cfg.framesPerBatch;
         if (const char* e = getenv("RTX_BATCH")) want = (uint64_t)std::max(1, atoi(e));
         while (want > 1 && (uint64_t)r->numSlots * want > 0x7fffff00ull) --want;
         r->batch = (int)std::max<uint64_t>(1, std::min<uint64_t>(RTX_MAX_BATCH, want));
@@ -981,6 +985,7 @@ static int build_renderer(const RtxSceneDesc* scene, const RtxConfig& cfg, const
     int hwQueues = 4;
     if (const char* e = getenv("GPU_MAX_HW_QUEUES")) hwQueues = std::max(1, atoi(e));
     int depth = cfg.framesInFlight > 0 ? cfg.framesInFlight : (hwQueues <= 4 ? std::max(1, hwQueues - 1) : std::min(hwQueues - 2, 14));
+    if (cfg.framesInFlight <= 0 && cfg.worldSize == 1 && r->batch > 1) depth = std::min(depth, std::max(3, 24 / r->batch));   // 8 at a time: 3 batches (queues of 9 M slots x 8 each)
     if (const char* e = getenv("RTX_FRAMES_IN_FLIGHT")) depth = atoi(e);
     depth = std::max(1, std::min(depth, kLag));
     r->ctx.resize((size_t)depth);
@@ -1072,7 +1077,8 @@ static int render_batch(RtxRenderer* r, const std::pair<RtxCamera, uint32_t>* fr
     {   // queue lengths of this context's previous batch, if they have arrived
         RtxRenderer::FrameCtx& c = r->ctx[r->active];
         if (c.countsPending && hipEventQuery(c.countsReady) == hipSuccess) {
-            for (int b = 1; b < 4; ++b) r->queueHint[b] = c.hCounts[b];
+            // the hints describe a full batch
+            for (int b = 1; b < 4; ++b) r->queueHint[b] = (uint32_t)std::min<uint64_t>((uint64_t)r->numSlots * r->batch, (uint64_t)c.hCounts[b] * r->batch / std::max(1, c.countsFrames));
             c.countsPending = false;
         }
     }
@@ -1086,7 +1092,7 @@ static int render_batch(RtxRenderer* r, const std::pair<RtxCamera, uint32_t>* fr
         int in = 0;
         for (int b = 0; b < 4; ++b) {
             if (b > 0) {
-                set_grids(r, std::min(slots, std::min(r->queueHint[b], r->queueHint[b - 1])));
+                set_grids(r, std::min(slots, (uint32_t)((uint64_t)std::min(r->queueHint[b], r->queueHint[b - 1]) * count / r->batch)));
                 dispatch_trace(r, r->dRqO[in], r->dRqD[in], b, 2 * b, 0);
                 HIP_TRY(hipEventRecord(ev[2 * b + 1], r->stream));
             }
@@ -1099,7 +1105,8 @@ static int render_batch(RtxRenderer* r, const std::pair<RtxCamera, uint32_t>* fr
         if (!ahead && queue_resolve(r, bt)) return 1;
         {
             RtxRenderer::FrameCtx& c = r->ctx[r->active];
-            if (!c.countsPending && count == r->batch) {       // hints describe full batches
+            if (!c.countsPending) {
+                c.countsFrames = count;
                 HIP_TRY(hipMemcpyAsync(c.hCounts, r->dCtrl, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, r->stream));
                 HIP_TRY(hipEventRecord(c.countsReady, r->stream));
                 c.countsPending = true;
@@ -1246,7 +1253,7 @@ static int gather_group(RtxRenderer* r) {
 }
 
 static bool delivers_with_look_ahead(const RtxRenderer* r) {
-    return r->lookAhead > 0 && r->batch == 1 && r->peers.empty() && !r->leader && r->copyStream && !getenv("RTX_PLAIN_COPY");
+    return r->lookAhead > 0 && r->peers.empty() && !r->leader && r->copyStream && !getenv("RTX_PLAIN_COPY");
 }
 
 // Hands the image back: the float frame, or (present) its 8-bit conversion. Waits for the resolve that was queued last —
@@ -1291,24 +1298,26 @@ int rtx_render(RtxRenderer* r, const RtxCamera* camera, uint32_t frameCounter, f
 }
 
 static int render_one(RtxRenderer* r, const RtxCamera* camera, uint32_t frameCounter, float* pixels_rgba) {
+    const bool ahead = delivers_with_look_ahead(r);
+    if (ahead) {
+        const bool predicted = r->haveLast && frameCounter == r->lastFc + 1u && memcmp(camera, &r->lastCam, sizeof(RtxCamera)) == 0;
+        r->streak = predicted ? r->streak + 1 : 0;
+        r->haveLast = true; r->lastCam = *camera; r->lastFc = frameCounter; r->rendersSinceDelivery++;
+        if (!r->ahead.empty() && r->ahead.front().fc == frameCounter && memcmp(camera, &r->ahead.front().cam, sizeof(RtxCamera)) == 0) {
+            if (take_ahead(r)) return 1;           // (nothing is collected at this point: frames are started ahead by a delivery, which renders the collection first)
+            return pixels_rgba ? deliver(r, false, 0.0f, pixels_rgba) : 0;
+        }
+        r->ahead.clear();                          // started for nothing
+    }
     if (!pixels_rgba && r->batch > 1) {
         // nothing has to be delivered yet: collect the frame; a full batch is rendered by one set of launches
         r->queued.emplace_back(*camera, frameCounter);
         if ((int)r->queued.size() >= r->batch) return flush_queued(r);
         return 0;
     }
-    if (delivers_with_look_ahead(r)) {
-        const bool predicted = r->haveLast && frameCounter == r->lastFc + 1u && memcmp(camera, &r->lastCam, sizeof(RtxCamera)) == 0;
-        r->streak = predicted ? r->streak + 1 : 0;
-        if (!r->ahead.empty() && r->ahead.front().fc == frameCounter && memcmp(camera, &r->ahead.front().cam, sizeof(RtxCamera)) == 0) {
-            if (take_ahead(r)) return 1;
-        } else {
-            r->ahead.clear();                      // started for nothing
-            if (render_frame(r, camera, frameCounter, false)) return 1;
-        }
-        r->haveLast = true; r->lastCam = *camera; r->lastFc = frameCounter; r->rendersSinceDelivery++;
-        if (!pixels_rgba) return 0;
-        return deliver(r, false, 0.0f, pixels_rgba);
+    if (ahead) {
+        if (render_frame(r, camera, frameCounter, false)) return 1;
+        return pixels_rgba ? deliver(r, false, 0.0f, pixels_rgba) : 0;
     }
     if (render_frame(r, camera, frameCounter, false)) return 1;
     if (pixels_rgba) return copy_out(r, pixels_rgba);

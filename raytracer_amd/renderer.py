@@ -16,7 +16,7 @@ from ._capi import Camera, Config, Counters, Info, SceneDesc
 
 class HIPShader:
     def __init__(self, scene, device=0, rank=0, world_size=1, tile=(64, 32), traversal=_capi.TRAVERSE_WIDE,
-                 count_stats=False, frames_in_flight=0, devices=None, look_ahead=0):
+                 count_stats=False, frames_in_flight=0, devices=None, look_ahead=0, frames_per_batch=0):
         """`scene` is a raytracer_amd.scene.HostScene (or anything with .desc() and
         .camera); its arrays are read once, here (as src/CLShader.cpp:20-49 does)."""
         self._L = _capi.hip_lib()
@@ -26,7 +26,7 @@ class HIPShader:
         self.frame_counter = 0                     # context->frameCounter
         cfg = Config(device=device, rank=rank, worldSize=world_size, tileW=tile[0], tileH=tile[1],
                      traversal=traversal, countStats=1 if count_stats else 0, framesInFlight=frames_in_flight,
-                     lookAhead=look_ahead)
+                     lookAhead=look_ahead, framesPerBatch=frames_per_batch)
         if devices is not None:            # a device group in this process (RtxConfig.numDevices / devices)
             cfg.numDevices = len(devices)
             for i, dev in enumerate(devices):

@@ -330,7 +330,7 @@ def test_frame_batches_render_the_serial_frames(scene2, synth_small, monkeypatch
     its own camera and frameCounter: the image must be the one the frame-by-frame path produces, bit for bit —
     with full batches, a partial batch at the end, a restart of the mean and a camera change inside a batch."""
     from raytracer_amd.scene import orbit
-    for scene, world, rank, forced in ((scene2, 4, 1, None), (synth_small, 8, 3, None), (scene2, 1, 0, "3")):
+    for scene, world, rank, forced in ((scene2, 4, 1, None), (synth_small, 8, 3, None), (scene2, 1, 0, "3"), (synth_small, 1, 0, None)):     # None: the default (8 on a single rank)
         d = scene.desc()
         frames = (0, 1, 2, 3, 4, 0, 1, 2, 3, 4, 5)           # 11 frames: partial last batch whatever the batch size
         out = {}
