@@ -13,7 +13,8 @@ replicated on every GPU, screen tiles dealt round-robin to the ranks. Total work
 the same for every N (strong scaling).
 
 What `value` is: rays traced by all ranks / wall time of { K x rtx_render(pixels = NULL) in the library's DEFAULT
-traversal mode (RTX_TRAVERSE_WIDE: the reference's result by construction) ; gather of the tiles to rank 0 (RCCL) ;
+traversal mode (RTX_TRAVERSE_WIDE: the reference's result by construction) and default configuration (queued frames are
+rendered config.frames_per_batch at a time, config.frames_in_flight batches overlap) ; gather of the tiles to rank 0 (RCCL) ;
 one device-to-host copy of the finished frame } — the delivered-batch pattern of BASELINE.json configs[3] (64 spp,
 one image). Scene and running mean are resident in HBM when the clock starts. Printed beside it, as top-level keys
 of the same line:
