@@ -63,6 +63,22 @@ def test_c_header_layout_static_asserts(tmp_path):
     subprocess.check_call(["g++", "-std=c++17", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), str(src)])
 
 
+def test_ctypes_mirrors_of_config_info_counters_match_the_header(tmp_path):
+    """RtxConfig / RtxInfo / RtxCounters as the Python binding declares them must be what a C caller of include/rtx.h sees."""
+    import subprocess
+    from raytracer_amd import _capi
+    src = tmp_path / "sizes.c"
+    src.write_text('#include "rtx.h"\n#include <stddef.h>\n#include <stdio.h>\n'
+                   'int main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(RtxConfig), offsetof(RtxConfig, numDevices), offsetof(RtxConfig, lookAhead), '
+                   'offsetof(RtxConfig, framesPerBatch), sizeof(RtxInfo), offsetof(RtxInfo, lookAhead), sizeof(RtxCounters), offsetof(RtxCounters, wavePasses));return 0;}\n')
+    exe = tmp_path / "sizes"
+    subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(src)])      # the header is C
+    got = [int(x) for x in subprocess.check_output([str(exe)], text=True).split()]
+    C, I, K = _capi.Config, _capi.Info, _capi.Counters
+    assert got == [ctypes.sizeof(C), C.numDevices.offset, C.lookAhead.offset, C.framesPerBatch.offset,
+                   ctypes.sizeof(I), I.lookAhead.offset, ctypes.sizeof(K), K.wavePasses.offset]
+
+
 def test_hip_backend_has_no_cpu_fallback(monkeypatch):
     """The product path fails loudly when the HIP library is missing."""
     from raytracer_amd import _capi
