@@ -168,8 +168,7 @@ typedef struct RtxConfig {
     int32_t framesPerBatch;/* frames queued with pixels_rgba == NULL are collected and rendered `framesPerBatch` at a time by
                               one set of launches (longer queues: the thin ends of the launches are shared by the frames of a
                               batch); any call that needs results renders what has been collected first, so results do not
-                              depend on it. 0 -> 8 on a single rank (ranks of a process group: as many as make the rank's queues
-                              a whole frame long), at most 8; 1 -> every frame is launched by the call that queues it.
+                              depend on it. 0 -> 8, at most 8; 1 -> every frame is launched by the call that queues it.
                               Each frame of a batch in flight holds about 125 B per pixel of this rank's tiles. */
 } RtxConfig;
 

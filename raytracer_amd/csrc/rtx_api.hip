@@ -948,12 +948,10 @@ static int build_renderer(const RtxSceneDesc* scene, const RtxConfig& cfg, const
 
     // per-path state (indexed by slot) and queues (indexed by queue position; the bounce queues hold
     // up to one unfinished run of holes per shade wave on top of the live rays)
-    // frames per batch: on a rank of a process group as many as make the rank's queues about as long as a whole frame's;
-    // on a single rank 8 (measured at 4K / 10 M triangles, queued frames: 6.58 ms per frame one at a time with 14 in
+    // frames per batch: 8, whatever the rank's share of the tiles (measured at 4K / 10 M triangles, queued frames: 6.58 ms per frame one at a time with 14 in
     // flight, 6.27 / 6.06 / 5.95 ms in batches of 2 / 4 / 8 — the launches' thin ends are shared by the frames of a batch)
     {
-        const uint64_t allSlots = (uint64_t)r->tilesX * r->tilesY * r->tileW * r->tileH;
-        uint64_t want = cfg.worldSize > 1 ? (r->numSlots ? allSlots / r->numSlots : 1) : RTX_MAX_BATCH;
+        uint64_t want = RTX_MAX_BATCH;
         if (cfg.framesPerBatch > 0) want = (uint64_t)cfg.framesPerBatch;
         if (const char* e = getenv("RTX_BATCH")) want = (uint64_t)std::max(1, atoi(e));
         while (want > 1 && (uint64_t)r->numSlots * want > 0x7fffff00ull) --want;
@@ -983,7 +981,9 @@ static int build_renderer(const RtxSceneDesc* scene, const RtxConfig& cfg, const
     int hwQueues = 4;
     if (const char* e = getenv("GPU_MAX_HW_QUEUES")) hwQueues = std::max(1, atoi(e));
     int depth = cfg.framesInFlight > 0 ? cfg.framesInFlight : (hwQueues <= 4 ? std::max(1, hwQueues - 1) : std::min(hwQueues - 2, 14));
-    if (cfg.framesInFlight <= 0 && cfg.worldSize == 1 && r->batch > 1) depth = std::min(depth, std::max(3, 24 / r->batch));   // 8 at a time: 3 batches (queues of 9 M slots x 8 each)
+    // about 24 whole frames' worth of queues in flight at most, whatever the share of the tiles: 3 batches of 8 on a single rank
+    // (9 M slots x 8 each at 4K), up to 14 batches of 8 on a rank that owns an eighth of them
+    if (cfg.framesInFlight <= 0 && r->batch > 1) depth = std::min(depth, std::max(3, 24 * cfg.worldSize / r->batch));
     if (const char* e = getenv("RTX_FRAMES_IN_FLIGHT")) depth = atoi(e);
     depth = std::max(1, std::min(depth, kLag));
     r->ctx.resize((size_t)depth);
