@@ -132,6 +132,7 @@ struct RtxRenderer {
     RtxRenderer* leader = nullptr;
     float* dPackedOwn = nullptr;
     float* dPackedAtLeader = nullptr;
+    hipEvent_t arrived = nullptr;   // member: its packed tiles have landed on the leader's device
     int leaderDevice = -1;
     uint32_t* dPresent = nullptr;    // rtx_present_rgba8: the 8-bit image on the device (allocated on first use)
     std::vector<float> hostStage;   // D2H staging for worldSize > 1
@@ -742,6 +743,7 @@ void rtx_destroy(RtxRenderer* r) {
     for (RtxRenderer* m : r->peers) { m->leader = nullptr; rtx_destroy(m); }
     r->peers.clear();
     hipSetDevice(r->device);
+    if (r->arrived) hipEventDestroy(r->arrived);
     if (r->dPackedOwn) hipFree(r->dPackedOwn);
     if (r->dPresent) hipFree(r->dPresent);
     if (r->dPackedAtLeader && r->leaderDevice >= 0) { hipSetDevice(r->leaderDevice); hipFree(r->dPackedAtLeader); hipSetDevice(r->device); }
@@ -1234,18 +1236,44 @@ static int copy_out(RtxRenderer* r, float* pixels) {
     return 0;
 }
 
-// Device group: every member's tiles into the leader's resident framebuffer. Packs on each member's device, one
-// peer copy per member (xGMI between GPUs), unpack on the leader. Once per delivered frame.
+// Device group: every member's tiles into the leader's resident framebuffer, once per delivered frame. Nothing in it waits
+// on the host until the end: a member's pack rides on the stream of the context that resolved last on that member (behind
+// its last resolve; the resolves are chained), the peer copy (xGMI between GPUs) behind the pack, and an event marks the
+// arrival at the leader; the leader's unpacks wait for those events on the stream behind its own last resolve. The members
+// work side by side — packs on their own devices, copies on their own links.
 static int gather_group(RtxRenderer* r) {
     if (r->peers.empty()) return 0;
-    if (sync_all(r)) return 1;
-    for (RtxRenderer* m : r->peers) if (rtx_pack_tiles(m, m->dPackedOwn)) return 1;          // completes m's queued frames first
+    drop_ahead(r);
+    if (flush_queued(r)) return 1;
     for (RtxRenderer* m : r->peers) {
-        const size_t bytes = (size_t)rtx_packed_floats(m, m->cfg.rank) * sizeof(float);
-        if (bytes) HIP_TRY(hipMemcpyPeer(m->dPackedAtLeader, r->device, m->dPackedOwn, m->device, bytes));
+        HIP_TRY(hipSetDevice(m->device));
+        if (flush_queued(m)) return 1;
+        const uint64_t total = (uint64_t)m->localTiles.size() * m->tileW * m->tileH;
+        const hipStream_t ms = m->lastResolved >= 0 ? m->ctx[m->lastResolved].stream : m->stream;
+        if (total) {
+            RtxCamera dummy{}; const DevFrame fr = make_frame(m, &dummy, 0);
+            hipLaunchKernelGGL(k_pack_tiles, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, ms, fr, m->dTiles,
+                               (int)m->localTiles.size(), m->dFb, (float4*)m->dPackedOwn);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemcpyPeerAsync(m->dPackedAtLeader, r->device, m->dPackedOwn, m->device, total * sizeof(float4), ms));
+        }
+        if (!m->arrived) HIP_TRY(hipEventCreateWithFlags(&m->arrived, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(m->arrived, ms));
     }
     HIP_TRY(hipSetDevice(r->device));
-    for (RtxRenderer* m : r->peers) if (rtx_unpack_tiles(r, m->dPackedAtLeader, m->cfg.rank)) return 1;
+    const hipStream_t ls = r->lastResolved >= 0 ? r->ctx[r->lastResolved].stream : r->stream;
+    for (RtxRenderer* m : r->peers) {
+        HIP_TRY(hipStreamWaitEvent(ls, m->arrived, 0));
+        const int src = m->cfg.rank;
+        const uint64_t total = (uint64_t)r->tilesOfRank[src].size() * r->tileW * r->tileH;
+        if (!total) continue;
+        RtxCamera dummy{}; const DevFrame fr = make_frame(r, &dummy, 0);
+        hipLaunchKernelGGL(k_unpack_tiles, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, ls, fr, r->dTilesOfRank[src],
+                           (int)r->tilesOfRank[src].size(), (const float4*)m->dPackedAtLeader, r->dFb);
+        HIP_TRY(hipGetLastError());
+    }
+    // the caller copies the frame out next (on whatever stream is current), and the members may be given new frames
+    HIP_TRY(hipStreamSynchronize(ls));
     return 0;
 }
 
