@@ -164,7 +164,7 @@ typedef struct RtxConfig {
                               running mean) before it copies the current one out; the next call either asks for the
                               first of them or they are dropped unused. Results and counters are the same either way;
                               a wrong guess costs device time only. 0 -> up to 3, at most framesInFlight - 1 (2 with
-                              HIP's default 4 hardware queues); -1 -> never. */
+                              HIP's default 4 hardware queues); -1 -> never. A device group looks ahead on all its members. */
     int32_t framesPerBatch;/* frames queued with pixels_rgba == NULL are collected and rendered `framesPerBatch` at a time by
                               one set of launches (longer queues: the thin ends of the launches are shared by the frames of a
                               batch); any call that needs results renders what has been collected first, so results do not

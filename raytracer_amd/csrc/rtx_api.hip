@@ -827,7 +827,7 @@ int rtx_create(const RtxSceneDesc* scene, const RtxConfig* cfgIn, RtxRenderer** 
     std::vector<RtxRenderer*> members;
     for (int i = 0; i < cfg.numDevices; ++i) {
         RtxConfig c = cfg;
-        c.device = cfg.devices[i]; c.rank = i; c.worldSize = cfg.numDevices; c.numDevices = 0;
+        c.device = cfg.devices[i]; c.rank = i; c.worldSize = cfg.numDevices; c.numDevices = -1;      // -1: a member of a device group
         RtxRenderer* m = nullptr;
         if (build_renderer(scene, c, flat, useBVH, createClock, &raw, &m)) { for (RtxRenderer* x : members) rtx_destroy(x); return 1; }
         members.push_back(m);
@@ -1011,7 +1011,7 @@ static int build_renderer(const RtxSceneDesc* scene, const RtxConfig& cfg, const
     }
     r->lookAhead = cfg.lookAhead < 0 ? 0 : std::min(cfg.lookAhead > 0 ? cfg.lookAhead : 3, depth - 1);       // 2 with HIP's default 4 hardware queues (3 contexts)
     if (const char* e = getenv("RTX_LOOKAHEAD")) r->lookAhead = std::max(0, std::min(atoi(e), depth - 1));
-    if (cfg.worldSize != 1) r->lookAhead = 0;       // a rank of a process group delivers through the gather, once per batch
+    if (cfg.worldSize != 1 && cfg.numDevices != -1) r->lookAhead = 0;       // a rank of a process group delivers through its own gather, once per batch (a device group looks ahead on all members)
     activate(r, 0);
     for (int b = 0; b < 4; ++b) r->queueHint[b] = r->numSlots * (uint32_t)r->batch;
     set_grids(r, r->numSlots * (uint32_t)r->batch);
@@ -1241,12 +1241,13 @@ static int copy_out(RtxRenderer* r, float* pixels) {
 // its last resolve; the resolves are chained), the peer copy (xGMI between GPUs) behind the pack, and an event marks the
 // arrival at the leader; the leader's unpacks wait for those events on the stream behind its own last resolve. The members
 // work side by side — packs on their own devices, copies on their own links.
-static int gather_group(RtxRenderer* r) {
+static int gather_group(RtxRenderer* r, bool keepAhead = false, hipStream_t* leaderStream = nullptr) {
     if (r->peers.empty()) return 0;
-    drop_ahead(r);
+    if (!keepAhead) drop_ahead(r);
     if (flush_queued(r)) return 1;
     for (RtxRenderer* m : r->peers) {
         HIP_TRY(hipSetDevice(m->device));
+        if (!keepAhead) drop_ahead(m);
         if (flush_queued(m)) return 1;
         const uint64_t total = (uint64_t)m->localTiles.size() * m->tileW * m->tileH;
         const hipStream_t ms = m->lastResolved >= 0 ? m->ctx[m->lastResolved].stream : m->stream;
@@ -1272,6 +1273,7 @@ static int gather_group(RtxRenderer* r) {
                            (int)r->tilesOfRank[src].size(), (const float4*)m->dPackedAtLeader, r->dFb);
         HIP_TRY(hipGetLastError());
     }
+    if (leaderStream) { *leaderStream = ls; return 0; }      // the caller goes on behind the unpacks on this stream
     // the caller copies the frame out next (on whatever stream is current), and the members may be given new frames
     HIP_TRY(hipStreamSynchronize(ls));
     return 0;
@@ -1317,6 +1319,37 @@ int rtx_render(RtxRenderer* r, const RtxCamera* camera, uint32_t frameCounter, f
     if (check_camera(camera)) return 1;
     if (r->leader) return fail("this renderer is a member of a device group: call its leader");
     if (r->peers.empty()) return render_one(r, camera, frameCounter, pixels_rgba);
+    if (r->lookAhead > 0 && !getenv("RTX_PLAIN_COPY")) {
+        // Device group in the loop "one frame, one delivery": the same look-ahead as a single renderer's (render_one / deliver),
+        // kept in step on all members — every member holds the same frames ahead, the leader keeps the books.
+        std::vector<RtxRenderer*> all{r};
+        all.insert(all.end(), r->peers.begin(), r->peers.end());
+        const bool predicted = r->haveLast && frameCounter == r->lastFc + 1u && memcmp(camera, &r->lastCam, sizeof(RtxCamera)) == 0;
+        r->streak = predicted ? r->streak + 1 : 0;
+        r->haveLast = true; r->lastCam = *camera; r->lastFc = frameCounter; r->rendersSinceDelivery++;
+        const bool match = !r->ahead.empty() && r->ahead.front().fc == frameCounter && memcmp(camera, &r->ahead.front().cam, sizeof(RtxCamera)) == 0;
+        for (RtxRenderer* m : all) {
+            if (match && !m->ahead.empty()) { if (take_ahead(m)) return 1; continue; }
+            m->ahead.clear();
+            if (!pixels_rgba && m->batch > 1) {
+                m->queued.emplace_back(*camera, frameCounter);
+                if ((int)m->queued.size() >= m->batch && flush_queued(m)) return 1;
+            } else if (render_frame(m, camera, frameCounter, false)) return 1;
+        }
+        if (!pixels_rgba) return 0;
+        hipStream_t ls = nullptr;
+        if (gather_group(r, true, &ls)) return 1;
+        const bool loop = r->rendersSinceDelivery == 1 && r->streak >= 1;
+        r->rendersSinceDelivery = 0;
+        while (loop && (int)r->ahead.size() < r->lookAhead) {
+            const std::pair<RtxCamera, uint32_t> next(*camera, frameCounter + 1u + (uint32_t)r->ahead.size());
+            for (RtxRenderer* m : all) if (render_batch(m, &next, 1, false, true)) return 1;
+        }
+        HIP_TRY(hipSetDevice(r->device));
+        const size_t bytes = (size_t)r->width * r->height * sizeof(float4);
+        if (stage_queue(r, ls, (const char*)r->dFb, bytes)) return 1;
+        return stage_deliver(r, (char*)pixels_rgba, bytes);
+    }
     // device group: the frame is queued on every member (their launches run side by side on their devices) ...
     if (render_one(r, camera, frameCounter, nullptr)) return 1;
     for (RtxRenderer* m : r->peers) if (render_one(m, camera, frameCounter, nullptr)) return 1;

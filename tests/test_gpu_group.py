@@ -64,6 +64,39 @@ def test_group_matches_the_oracle(scene1):
     grp.close()
 
 
+def test_group_looks_ahead_in_step_on_all_members(scene2):
+    """The synchronous loop on a device group: frames are started ahead on every member (rtx_api.hip rtx_render, group branch)
+    and taken, dropped or topped up in step. Every delivered frame and the counters must be those of a single renderer
+    that never looks ahead, bit for bit — through the loop, a jump of the frame counter, a camera change, queued frames,
+    a download and an upload in between."""
+    from raytracer_amd.scene import orbit
+    d, cam = scene2.desc(), scene2.camera
+    cam2 = type(cam).from_buffer_copy(cam); orbit(cam2, 25.0, 8.0, radius=2500.0)
+    start = np.random.default_rng(9).random((d.height, d.width, 4), dtype=np.float32)
+    script = [("r", (cam, 0)), ("r", (cam, 1)), ("r", (cam, 2)), ("r", (cam, 3)), ("r", (cam, 4)), ("r", (cam, 9)), ("r", (cam, 10)),
+              ("r", (cam2, 11)), ("r", (cam2, 12)), ("r", (cam2, 13)), ("q", (cam2, 14)), ("q", (cam2, 15)), ("r", (cam2, 16)), ("r", (cam2, 17)),
+              ("d", None), ("r", (cam2, 18)), ("r", (cam2, 19)), ("upload", start), ("r", (cam2, 20)), ("r", (cam2, 21)), ("r", (cam2, 22))]
+    logs = {}
+    for name, kw in (("one", dict(look_ahead=-1)), ("group", dict(devices=[0, 0, 0]))):
+        r = HIPShader(scene2, **kw)
+        if name == "group": assert r.info().lookAhead >= 1 and r.info().devices == 3
+        px = np.zeros((d.height, d.width, 4), np.float32)
+        log = []
+        for op, arg in script:
+            if op in ("r", "q"):
+                r.frame_counter = arg[1]
+                r.Render(px if op == "r" else None, arg[0])
+                if op == "r": log.append(px.copy())
+            elif op == "d": log.append(r.download())
+            elif op == "upload": r.upload(arg)
+        c = r.counters()
+        log.append(np.array(list(c.raysPerBounce) + list(c.hitsPerBounce), np.int64))
+        logs[name] = log
+        r.close()
+    for a, b in zip(logs["one"], logs["group"]):
+        assert (a.view(np.uint32) == b.view(np.uint32)).all()
+
+
 def test_group_rejects_bad_configurations(scene1):
     import ctypes as C
     L = _capi.hip_lib()
