@@ -5,6 +5,8 @@ and the committed golden fixtures. Bars (BASELINE.json north_star):
     (Measured: the framebuffers come out bit-identical; the tolerance is kept
     because the double-precision libm calls in the shading terms are not pinned
     bit for bit between glibc and the device libm.)"""
+import os
+
 import numpy as np
 import pytest
 
@@ -434,3 +436,28 @@ def test_look_ahead_of_the_synchronous_loop_is_invisible(scene2, monkeypatch):
     for fc in range(4):
         oracle.render(d, cam, fc, want, 8)
     check_fb(runs["2"][-2], want)
+
+
+def test_config_knobs_are_reported_and_do_not_change_results(scene1):
+    """RtxConfig.framesPerBatch / lookAhead / framesInFlight as resolved by rtx_create (rtx_get_info), and the same image
+    whatever they are."""
+    d = scene1.desc()
+    out = []
+    for kw, want in ((dict(), dict(framesPerBatch=8, lookAhead=2, framesInFlight=3)),
+                     (dict(frames_per_batch=1, look_ahead=-1, frames_in_flight=1), dict(framesPerBatch=1, lookAhead=0, framesInFlight=1)),
+                     (dict(frames_per_batch=3, look_ahead=1, frames_in_flight=2), dict(framesPerBatch=3, lookAhead=1, framesInFlight=2)),
+                     (dict(frames_per_batch=100, look_ahead=9, frames_in_flight=4), dict(framesPerBatch=8, lookAhead=3, framesInFlight=4))):
+        r = HIPShader(scene1, **kw)
+        i = r.info()
+        if os.environ.get("GPU_MAX_HW_QUEUES") in (None, "4") or kw:       # the defaults depend on the hardware queues of the process
+            for k, v in want.items():
+                assert getattr(i, k) == v, (kw, k, getattr(i, k), v)
+        px = np.zeros((d.height, d.width, 4), np.float32)
+        for f in range(5):
+            r.frame_counter = f; r.Render(None)
+        for f in range(5, 9):
+            r.frame_counter = f; r.Render(px)
+        out.append(px)
+        r.close()
+    for px in out[1:]:
+        assert (px.view(np.uint32) == out[0].view(np.uint32)).all()
