@@ -228,13 +228,16 @@ int rtx_create(const RtxSceneDesc* scene, const RtxConfig* cfg, RtxRenderer** ou
  * src/CLShader.cpp:160-166. pixels_rgba: host, width*height*4 floats, row-major
  * y*width+x; may be NULL to skip the device-to-host copy (the running mean
  * stays resident on the device either way): the call then only queues the frame
- * (camera and frameCounter are copied), frames overlap on the device
- * (RtxConfig.framesInFlight), and a rank that owns 1/N of the tiles renders up to
- * min(N, 8) queued frames with one set of launches; every entry point that
+ * (camera and frameCounter are copied): queued frames are rendered
+ * RtxConfig.framesPerBatch at a time by one set of launches, up to
+ * RtxConfig.framesInFlight batches overlap on the device; every entry point that
  * returns results (a later rtx_render with pixels, rtx_download_pixels,
  * rtx_get_counters, rtx_pack_tiles ...) completes all queued frames first, in
- * call order. With worldSize > 1 only this rank's tiles are written; other
- * pixels of pixels_rgba are left untouched. */
+ * call order. With pixels the call returns when the frame has been copied; in
+ * the loop "same camera, frameCounter + 1, one delivery per frame" the library
+ * starts the following frames before they are asked for (RtxConfig.lookAhead;
+ * results and counters are not affected). With worldSize > 1 only this rank's
+ * tiles are written; other pixels of pixels_rgba are left untouched. */
 int rtx_render(RtxRenderer* r, const RtxCamera* camera, uint32_t frameCounter, float* pixels_rgba);
 
 /* Parity probe for ThreadedShader::BVHTraverse / LinearTraverse on primary rays
