@@ -119,9 +119,10 @@ def main():
     if args.sync_only:
         return sync_only(args)
 
-    # frames are queued several deep, one stream each: give the process a hardware queue per stream
-    # (HIP reads this once, when the process first touches the GPU; its default is 4)
-    if int(os.environ.get("GPU_MAX_HW_QUEUES", "4")) < 16:
+    # One GPU: HIP's defaults (4 hardware queues per process; batches of 8 frames, 3 in flight need no more — measured equal
+    # with 16). Ranks of a multi-GPU run keep up to 14 shorter batches in flight, one stream each: they get a hardware
+    # queue per stream (HIP reads this once, when the process first touches the GPU).
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 and int(os.environ.get("GPU_MAX_HW_QUEUES", "4")) < 16:
         os.environ["GPU_MAX_HW_QUEUES"] = "16"
 
     rank = int(os.environ.get("RANK", "0"))

@@ -3,7 +3,6 @@
 # $1 = output tag (gpurun_out/prof_$1). Kernel trace first, then one --pmc pass per counter group.
 set -e
 export TMPDIR=/tmp
-export GPU_MAX_HW_QUEUES=16     # what bench.py sets for itself; exported so that the profiler's own HIP initialisation sees it too
 OUT=gpurun_out/prof_$1
 mkdir -p $OUT
 B="python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-extras ${RTX_PROF_ARGS:-}"
