@@ -7,7 +7,8 @@
  *
  * The POD structs below restate the reference's host layouts byte for byte
  * (sizes and offsets are asserted in tests/test_abi.py and, against the reference's own
- * structs, by the static_asserts of oracle/ref_parts.cpp)
+ * structs — Object, Material, BoundingBox, Texture, Camera —, by the static_asserts of
+ * oracle/ref_parts.cpp and tests/test_oracle.py)
  * so that a HIPShader : ComputeShader inside the reference can pass
  * context->objects.data() etc. straight through.
  *
@@ -251,8 +252,9 @@ int rtx_primary_hits(RtxRenderer* r, const RtxCamera* camera, uint32_t frameCoun
 int rtx_trace_rays(RtxRenderer* r, const float* origins, const float* directions, uint64_t n,
                    int32_t* objectIDs, float* points, float* normals);
 
-/* rtx_trace_rays for callers that cannot allocate. NO COUNTERPART IN THE REFERENCE: it exists for code under HIP graph
- * capture, tight serving loops and harnesses that forbid hipMalloc. Same kernels and results as rtx_trace_rays, but
+/* rtx_trace_rays for callers that cannot allocate. NO COUNTERPART IN THE REFERENCE: it exists for tight serving loops
+ * and harnesses that forbid hipMalloc / hipFree (it is a synchronous call on the renderer's own stream, so it cannot itself
+ * be recorded into a HIP graph). Same kernels, results and work counters (bounce-1 slots) as rtx_trace_rays, but
  * origins / directions / outputs are DEVICE pointers (n*4 floats, n ints, n*4, n*4; each output may be NULL) and the
  * intermediate buffers rtx_trace_rays allocates per call (work counters, hit distances, hit leaves, side list, staged
  * directions) live in one fixed file-scope device array of 14 MiB per GPU, held until the process ends. The call

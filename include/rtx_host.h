@@ -88,6 +88,8 @@ int rtxh_scene_set_camera(RtxHostScene* s, const RtxCamera* in);
 /* Camera::LookAt (src/Camera.h:51-55) and the orbit step of src/Main.cpp:68-82. */
 void rtxh_camera_look_at(RtxCamera* cam, const float target[3]);
 void rtxh_camera_orbit(RtxCamera* cam, float yawDeg, float pitchDeg, float radius);
+/* Camera::Rotate (src/Camera.h:26-43): yaw / pitch += offset * rotationSpeed, pitch clamped to +-89 degrees, basis rebuilt. */
+void rtxh_camera_rotate(RtxCamera* cam, double offsetX, double offsetY);
 
 /* Binary scene blob (the wire format between ingest and the C-ABI). */
 int rtxh_scene_save_blob(RtxHostScene* s, const char* path);

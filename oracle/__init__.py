@@ -93,6 +93,12 @@ def ref_parts():
         L.ref_vec_ops.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]
         L.ref_vec_geom.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]
         L.ref_color_ops.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]
+        if hasattr(L, "ref_camera_look_at"):
+            L.ref_camera_look_at.argtypes = [C.c_void_p, C.c_void_p]
+            L.ref_camera_rotate.argtypes = [C.c_void_p, C.c_double, C.c_double]
+            L.ref_box_layout.argtypes = [C.c_void_p]
+            L.ref_box_expand.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+            L.ref_box_expand.restype = C.c_float
         if hasattr(L, "ref_read_bmp"):
             L.ref_read_bmp.argtypes = [C.c_char_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_void_p, C.c_uint64]
             L.ref_read_bmp.restype = C.c_uint64

@@ -5,7 +5,7 @@
  * TEST INFRASTRUCTURE (checker only). Built by oracle/Makefile into
  * oracle/_ref/libref_parts.so, which is git-ignored. The reference sources are
  * compiled WHERE THEY LIE under $(REF)/src — nothing is copied into the repo:
- *     Shading.h, Camera.h, Vector3.h, Color.h, Material.h, Object.h, Texture.h,
+ *     Shading.h, Camera.h, BoundingBox.h, Vector3.h, Color.h, Material.h, Object.h, Texture.h,
  *     SpatialType.h, Random.h, BitmapReader.h  (included below by path)
  *     Random.cpp, BitmapReader.cpp             (compiled as their own translation units)
  *
@@ -20,6 +20,9 @@
 #include "Camera.h"
 #include "Random.h"
 #include "BitmapReader.h"
+#include "BoundingBox.h"
+
+#include <cstddef>
 
 #include <cstdint>
 #include <cstring>
@@ -87,6 +90,41 @@ void ref_color_ops(const float* a4, const float* b4, float t, float* out /* 3 x 
     Color r[3];
     r[0] = Color::Lerp(a, b, t); r[1] = Color::Clamp(a); r[2] = a * b;
     memcpy(out, r, sizeof(r));
+}
+
+// Camera::LookAt / Camera::Rotate (src/Camera.h:26-55) on a 96-byte camera, in place
+void ref_camera_look_at(void* camera96, const float* target3) {
+    Camera cam; memcpy((void*)&cam, camera96, 96);
+    cam.LookAt(V(target3));
+    memcpy(camera96, (void*)&cam, 96);
+}
+void ref_camera_rotate(void* camera96, double offsetX, double offsetY) {
+    Camera cam; memcpy((void*)&cam, camera96, 96);
+    cam.Rotate(offsetX, offsetY);
+    memcpy(camera96, (void*)&cam, 96);
+}
+
+// BoundingBox (src/BoundingBox.h:7-48): layout as include/rtx.h RtxBoundingBox states it, and the default box
+static_assert(sizeof(BoundingBox) == 64 && alignof(BoundingBox) == 64, "BoundingBox layout");
+static_assert(offsetof(BoundingBox, objectID) == 0 && offsetof(BoundingBox, parentID) == 4 && offsetof(BoundingBox, leftID) == 8 &&
+              offsetof(BoundingBox, rightID) == 12 && offsetof(BoundingBox, minimalPosition) == 16 && offsetof(BoundingBox, maximalPosition) == 32,
+              "BoundingBox offsets");
+static_assert(offsetof(Camera, front) == 0 && offsetof(Camera, up) == 16 && offsetof(Camera, right) == 32 && offsetof(Camera, position) == 48 &&
+              offsetof(Camera, aspectRatio) == 72 && offsetof(Camera, nearView) == 76 && offsetof(Camera, fov) == 84 &&
+              offsetof(Camera, pitch) == 88 && offsetof(Camera, yaw) == 92, "Camera offsets");
+static_assert(offsetof(Object, type) == 0 && offsetof(Object, radius) == 4 && offsetof(Object, position) == 16 && offsetof(Object, normals) == 32 &&
+              offsetof(Object, vertices) == 80 && offsetof(Object, uvs) == 128 && offsetof(Object, materialID) == 176, "Object offsets");
+void ref_box_layout(int32_t* out8) {      // sizes / offsets for a run-time comparison with the ctypes / numpy mirrors
+    out8[0] = (int32_t)sizeof(BoundingBox); out8[1] = (int32_t)offsetof(BoundingBox, objectID); out8[2] = (int32_t)offsetof(BoundingBox, parentID);
+    out8[3] = (int32_t)offsetof(BoundingBox, leftID); out8[4] = (int32_t)offsetof(BoundingBox, rightID);
+    out8[5] = (int32_t)offsetof(BoundingBox, minimalPosition); out8[6] = (int32_t)offsetof(BoundingBox, maximalPosition); out8[7] = (int32_t)alignof(BoundingBox);
+}
+// default-constructed box, then Expand()ed by `n` boxes given as 64-byte records; SurfaceArea() of the result
+float ref_box_expand(const void* boxes64, int n, void* out64) {
+    BoundingBox acc;
+    for (int i = 0; i < n; ++i) { BoundingBox b; memcpy((void*)&b, (const char*)boxes64 + 64 * (size_t)i, 64); acc.Expand(b); }
+    memcpy(out64, (void*)&acc, 64);
+    return acc.SurfaceArea();
 }
 
 // BitmapReader::ReadFile (src/BitmapReader.cpp:70-137): texels as the reference unpacks them

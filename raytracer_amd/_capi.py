@@ -126,6 +126,8 @@ def host_lib():
         L.rtxh_camera_look_at.restype = None
         L.rtxh_camera_orbit.argtypes = [C.POINTER(Camera), C.c_float, C.c_float, C.c_float]
         L.rtxh_camera_orbit.restype = None
+        L.rtxh_camera_rotate.argtypes = [C.POINTER(Camera), C.c_double, C.c_double]
+        L.rtxh_camera_rotate.restype = None
         L.rtxh_scene_from_arrays.restype = C.c_void_p
         L.rtxh_scene_from_arrays.argtypes = [C.POINTER(SceneDesc), C.POINTER(Camera), C.c_uint32]
         L.rtxh_scene_load_blob.restype = C.c_void_p
@@ -179,5 +181,5 @@ EXPORTED_HOST = ["rtxh_scene_new", "rtxh_scene_free", "rtxh_scene_set_resolution
                  "rtxh_scene_load_obj", "rtxh_scene_material_id", "rtxh_scene_add_texture", "rtxh_scene_add_material",
                  "rtxh_scene_add_plane", "rtxh_scene_add_disk", "rtxh_scene_add_cube", "rtxh_scene_add_sphere",
                  "rtxh_scene_add_mesh", "rtxh_scene_add_heightfield", "rtxh_write_heightfield_obj", "rtxh_scene_build_bvh", "rtxh_scene_from_arrays", "rtxh_scene_desc",
-                 "rtxh_scene_camera", "rtxh_scene_set_camera", "rtxh_camera_look_at", "rtxh_camera_orbit",
+                 "rtxh_scene_camera", "rtxh_scene_set_camera", "rtxh_camera_look_at", "rtxh_camera_orbit", "rtxh_camera_rotate",
                  "rtxh_scene_save_blob", "rtxh_scene_load_blob", "rtxh_last_error"]

@@ -1,5 +1,5 @@
 // rtx_run — headless driver for the HIP backend with the reference's flags
-// (src/Configurator.cpp:78-142): -L <scn> -w <px> -h <px> -B -F <frames> -O,
+// (src/Configurator.cpp:78-142): -L <scn | scene.blob> -w <px> -h <px> -B -F <frames> -O,
 // plus -o <file.pfm|file.bmp> to write the frame (the reference's -F mode never
 // writes one, src/Main.cpp:46-54), -g <gamma> for the BMP, -N <triangles> for the synthetic scene, and
 // -P to run the windowed loop's hand-over headlessly (src/WindowManager.cpp:160-187: Render, then the frame goes to the
@@ -81,12 +81,17 @@ int main(int argc, char** argv) {
             case 'G': gpus = std::min(8, std::max(1, atoi(val("a number of GPUs")))); break;
             case 'P': present = true; break;
             case 'V': case 'S': break;
-            case 'H': printf("Usage: rtx_run [-L scene.scn | -N triangles] [-w W] [-h H] [-B] [-F frames] [-O] [-o out.pfm|out.bmp] [-g gamma (BMP only, e.g. 2.2)] [-G gpus] [-P]\n"); return 0;
+            case 'H': printf("Usage: rtx_run [-L scene.scn | -L scene.blob | -N triangles] [-w W] [-h H] [-B] [-F frames] [-O] [-o out.pfm|out.bmp] [-g gamma (BMP only, e.g. 2.2)] [-G gpus] [-P]\n"); return 0;
             default: fprintf(stderr, "Unknown argument: %s\n", a); return -1;
         }
     }
-    RtxHostScene* scene = rtxh_scene_new((uint32_t)w, (uint32_t)h);
-    if (scenePath && rtxh_scene_load_scn(scene, scenePath) != 0) { fprintf(stderr, "%s\n", rtxh_last_error()); return -1; }
+    // -L x.blob: a binary scene blob (the five arrays + camera + resolution as rtxh_scene_save_blob wrote them; -w / -h do
+    // not apply, the BVH comes with the blob) instead of a .scn text scene
+    const size_t pathLen = scenePath ? strlen(scenePath) : 0;
+    const bool blob = pathLen > 5 && strcmp(scenePath + pathLen - 5, ".blob") == 0;
+    RtxHostScene* scene = blob ? rtxh_scene_load_blob(scenePath) : rtxh_scene_new((uint32_t)w, (uint32_t)h);
+    if (!scene) { fprintf(stderr, "%s\n", rtxh_last_error()); return -1; }
+    if (scenePath && !blob && rtxh_scene_load_scn(scene, scenePath) != 0) { fprintf(stderr, "%s\n", rtxh_last_error()); return -1; }
     if (synth > 0) {
         RtxSceneDesc d; rtxh_scene_desc(scene, &d);
         const float aspect = (float)d.width / (float)d.height, scale = 100.0f * aspect;
@@ -102,7 +107,7 @@ int main(int argc, char** argv) {
         rtxh_scene_add_heightfield(scene, (uint64_t)synth, 12345, 2.1f * halfW / scale, 2.1f * halfH / scale, 60.0f / scale, 25.0f,
                                    (500 - d.width / 2.0f) / scale, (560 - d.height / 2.0f) / scale, 0.0f, mats, 1);
     }
-    if (bvh) rtxh_scene_build_bvh(scene, 8);
+    if (bvh && !blob) rtxh_scene_build_bvh(scene, 8);
 
     RenderingContext context;
     FillContext(context, scene);

@@ -141,6 +141,21 @@ void rtxh_camera_look_at(RtxCamera* cam, const float target[3]) {
     cam->right = unit(cross3(worldUp, cam->front));
     cam->up = unit(cross3(cam->front, cam->right));
 }
+// src/Camera.h:26-43 — the compound assignments and sin / cos / fmax / fmin run in double (float operands promoted)
+void rtxh_camera_rotate(RtxCamera* cam, double offsetX, double offsetY) {
+    const float deg2rad = 0.0174532925f;
+    const RtxVec4 worldUp = v4(0, 1, 0);
+    cam->yaw = (float)((double)cam->yaw + offsetX * (double)cam->rotationSpeed);
+    cam->pitch = (float)((double)cam->pitch + offsetY * (double)cam->rotationSpeed);
+    cam->pitch = (float)fmax((double)-89.0f, fmin((double)cam->pitch, (double)89.0f));
+    const float pitch2rad = cam->pitch * deg2rad;
+    const float yaw2rad = cam->yaw * deg2rad;
+    cam->front.x = (float)(cos((double)yaw2rad) * cos((double)pitch2rad));
+    cam->front.y = (float)sin((double)pitch2rad);
+    cam->front.z = (float)(sin((double)yaw2rad) * cos((double)pitch2rad));
+    cam->right = unit(cross3(worldUp, cam->front));
+    cam->up = unit(cross3(cam->front, cam->right));
+}
 // src/Main.cpp:68-77 — sin/cos are the double overloads of float arguments
 void rtxh_camera_orbit(RtxCamera* cam, float yawDeg, float pitchDeg, float radius) {
     const float deg2rad = 0.0174532925f;

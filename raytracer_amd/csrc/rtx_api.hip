@@ -43,6 +43,12 @@ static const int kMaxDevices = 64;
 static unsigned char* g_scratch[kMaxDevices] = {};      // per device: address of that device's copy of scratch[]
 static std::mutex g_scratchMutex;
 
+// work-list entries of the quantised walk at the limit flatten() enforces (rtx_traverse.h q_pass decodes with >> 4)
+static_assert((RTX_QENTRY(rtxbuild::kQuantMaxLeaves + 3, 15) >> 4) == rtxbuild::kQuantMaxLeaves + 3, "largest leaf base must survive the entry encoding");
+static_assert((RTX_QENTRY(-4, 15) >> 4) == -4 && (RTX_QENTRY(-4, 15) & 15) == 15, "pre-biased (negative) bases must survive the entry encoding");
+static_assert((RTX_QENTRY(1 << 27, 1) >> 4) != (1 << 27), "2^27 is where the encoding wraps: kQuantMaxLeaves must stay below it");
+static_assert(RTX_QENTRY(5, 3) == rtxbuild::q_entry(5, 3) && rtxbuild::q_entry_base(rtxbuild::q_entry(-2, 9)) == -2, "host mirror of the entry encoding");
+
 struct RtxRenderer;
 static const int kRing = 32;      // frames whose timing events are kept; a frame's timing is read kLag frames later
 static const int kLag = 16;
@@ -122,6 +128,7 @@ struct RtxRenderer {
     // timing
     hipEvent_t ev[kRing][kEvents];
     bool pending[kRing] = {};
+    bool aheadSlot[kRing] = {};      // the slot times a frame started ahead: its timing counts only once the frame is asked for
     int lastFinished = -1;           // ring slot of the frame whose timing was read last
     int ringPos = 0;
     RtxCounters totals{};
@@ -148,7 +155,7 @@ struct RtxRenderer {
     // resolve, with work counters of their own. The next rtx_render either asks for exactly the oldest of them (its resolve
     // is queued, its counters are added, and the look-ahead is topped up at the next delivery) or for something else (they
     // are dropped: their launches run out unused, nothing they wrote is ever read). Every other entry point drops them too.
-    struct Ahead { RtxCamera cam{}; uint32_t fc = 0; int ctx = -1; DevBatch bt{}; };
+    struct Ahead { RtxCamera cam{}; uint32_t fc = 0; int ctx = -1; DevBatch bt{}; int ringSlot = -1; };
     std::deque<Ahead> ahead;            // frames started ahead, oldest first: consecutive frame counters, one camera
     bool haveLast = false; RtxCamera lastCam{}; uint32_t lastFc = 0;      // the last frame asked for
     int streak = 0;                     // calls in a row that asked for (same camera, frame counter + 1)
@@ -341,6 +348,10 @@ int flatten(const RtxSceneDesc& s, bool useBVH, bool wantFast, bool wantQuant, i
     // is an error). The frontier keeps the left-to-right order of the tree, a subtree's walker numbers its leaves
     // locally, and a prefix sum over the frontier turns that into the global left-first rank.
     if (nLeaf >= (1 << 28)) return fail("too many leaves (2^28 or more)");
+    // the quantised walk packs (base << 4 | slot mask) into an int and decodes the base with an arithmetic shift (bases are
+    // pre-biased and may be negative): bases from 2^27 on would come back negative. Larger scenes walk the float nodes
+    // (same tree, same leaf set, no distance culling: RtxInfo.traversal still says WIDE).
+    if (nLeaf > rtxbuild::kQuantMaxLeaves) wantQuant = false;
     std::vector<int32_t, rtxbuild::NoInitAlloc<int32_t>> rankLocal((size_t)nLeaf), rankPart((size_t)nLeaf);   // per leaf: right-first index inside its part, part
     parallel_for((uint64_t)nLeaf, nthreads, [&](uint64_t k0, uint64_t k1) { for (uint64_t k = k0; k < k1; ++k) { rankLocal[k] = 0; rankPart[k] = 0; } });
     std::vector<int64_t> partBase;                                                   // per frontier entry: leaves left of it
@@ -462,7 +473,9 @@ int flatten(const RtxSceneDesc& s, bool useBVH, bool wantFast, bool wantQuant, i
             f.fastRoot = 0;
             f.seconds[1] += clock.lap("fold into 4-wide nodes");
         }
-    } else if (wantFast && f.nested && nLeaf <= 1) {
+    } else if (wantFast && f.nested && nLeaf <= 1 && !(nBox > 0 && s.boxes[0].objectID != -1)) {
+        // (a root box that is itself the leaf is never tested by the reference, src/ThreadedShader.cpp:349-368: such a
+        // one-object tree stays on the reference topology, where the primitive is intersected unconditionally)
         rtxbuild::Box b;
         if (nLeaf == 1) {
             const RtxBoundingBox& lb = s.boxes[leafBox[0]];
@@ -639,6 +652,10 @@ void set_grids(RtxRenderer* r, uint32_t expected) {
 
 void finish_timing(RtxRenderer* r, int slot) {
     if (!r->pending[slot]) return;
+    if (r->aheadSlot[slot]) {          // started ahead and never asked for: speculative device time is not the caller's
+        r->aheadSlot[slot] = false; r->pending[slot] = false;
+        return;
+    }
     hipEventSynchronize(r->ev[slot][kEvents - 1]);
     float total = 0, trace = 0, shade = 0, ms = 0;
     hipEventElapsedTime(&total, r->ev[slot][0], r->ev[slot][kEvents - 1]);
@@ -792,6 +809,7 @@ int rtx_create(const RtxSceneDesc* scene, const RtxConfig* cfgIn, RtxRenderer** 
             (uint64_t)t.offset + (uint64_t)t.width * (uint64_t)t.height > scene->numTexels)
             return fail("texture " + std::to_string(i) + ": extent outside textureData (or wider than 4096)");
     }
+    if (cfg.numDevices < 0) return fail("RtxConfig.numDevices must not be negative");
     if (cfg.numDevices > 1) {
         if (cfg.numDevices > 8) return fail("RtxConfig.numDevices: at most 8");
         if (cfg.worldSize != 1) return fail("a device group (numDevices > 1) cannot also be one rank of a process group (worldSize > 1)");
@@ -1114,7 +1132,8 @@ static int render_batch(RtxRenderer* r, const std::pair<RtxCamera, uint32_t>* fr
         HIP_TRY(hipEventRecord(ev[kEvents - 1], r->stream));
         r->pending[slot] = true;
         if (ahead) {
-            r->ahead.push_back(RtxRenderer::Ahead{frames[0].first, frames[0].second, r->active, bt});
+            r->aheadSlot[slot] = true;
+            r->ahead.push_back(RtxRenderer::Ahead{frames[0].first, frames[0].second, r->active, bt, slot});
         } else {
             r->totals.frames += (uint64_t)count;
             r->primaryRays += r->localPixels * (uint64_t)count;
@@ -1134,6 +1153,7 @@ static int take_ahead(RtxRenderer* r) {
     HIP_TRY(hipGetLastError());
     r->totals.frames += 1;
     r->primaryRays += r->localPixels;
+    if (r->ahead.front().ringSlot >= 0) r->aheadSlot[r->ahead.front().ringSlot] = false;      // its device time counts from here on
     r->ahead.pop_front();
     return 0;
 }
@@ -1501,11 +1521,12 @@ int rtx_trace_rays_noalloc(RtxRenderer* r, const float* d_origins, const float* 
     const uint32_t cnt = (uint32_t)n;
     // the array keeps the last call's contents: the counters must start at zero, the queue length is this call's
     HIP_TRY(hipMemsetAsync(sCtrl, 0, RTX_CTRL_WORDS * sizeof(uint32_t), r->stream));
+    HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)(sCtrl + RTX_CTRL_COUNT(1)), (int)cnt, 1, r->stream));
     hipLaunchKernelGGL(k_stage_directions, dim3((cnt + 255u) / 256u), dim3(256), 0, r->stream, (const float4*)d_directions, sD, cnt);
     int2* saveH = r->dHit; uint32_t* saveS = r->dSlow; uint32_t* saveC = r->dCtrl;
     r->dHit = sH; r->dSlow = sSlow; r->dCtrl = sCtrl;
     set_grids(r, cnt);
-    dispatch_trace(r, (const float4*)d_origins, sD, 0, 0, cnt);        // countIdx 0: the queue length travels as an argument
+    dispatch_trace(r, (const float4*)d_origins, sD, 1, 0, 0);          // counted like rtx_trace_rays: as a bounce-1 queue
     r->dHit = saveH; r->dSlow = saveS; r->dCtrl = saveC;
     hipLaunchKernelGGL(k_probe_finish, dim3((cnt + 255u) / 256u), dim3(256), 0, r->stream, r->sc, r->linear ? 1 : 0,
                        (const float4*)d_origins, sD, sH, cnt, d_objectIDs, (float4*)d_points, (float4*)d_normals);

@@ -653,6 +653,14 @@ inline void single_leaf_node4(const Box* leafBox, Raw<Node4>& out) {
 #ifndef RTX_QNODE_WORDS
 #define RTX_QNODE_WORDS 16      // words from one node to the next: 16 = one node per 64-byte slot, 12 = packed
 #endif
+// Work-list entries of the quantised walk (rtx_traverse.h RTX_QENTRY / q_pass): children base + j of one node for every set
+// bit j of the mask, as base << 4 | mask in an int; the base comes back through an arithmetic shift, because the bases are
+// pre-biased (baseLeaf = first leaf child - number of inner children) and may be as low as -4. So bases must stay below
+// 2^27: rtx_create only quantises trees of at most kQuantMaxLeaves leaves (a node index is always below the leaf count).
+constexpr int32_t kQuantMaxLeaves = (1 << 27) - 4;
+constexpr int32_t q_entry(int32_t base, uint32_t mask) { return (int32_t)(((uint32_t)base << 4) | mask); }
+constexpr int32_t q_entry_base(int32_t e) { return e >> 4; }
+
 struct NodeQ {          // 48 bytes used
     // w[0..2] origin.xyz  w[3] = ex | ey << 8 | ez << 16 | valid << 24 | leaf << 28   (e* = biased float exponent of the step)
     // w[4] lo.x bytes (slot j in byte j)  w[5] hi.x  w[6] lo.y  w[7] hi.y  w[8] lo.z  w[9] hi.z  w[10] baseInner  w[11] baseLeaf

@@ -137,8 +137,11 @@ __device__ __forceinline__ Hit closest_hit(const DevScene& sc, float ox, float o
     const long long gtid = (long long)blockIdx.x * RTX_BLOCK + threadIdx.x;
     if (MODE == RTX_MODE_WIDEQ || MODE == RTX_MODE_WIDEQ_BIG) {
         if (clean) {
+            // the spill column is the one the reference-topology walk below uses for a lane that is not clean: int2
+            // column gtid, ints 2 * nthreads apart. A lane is either clean or not, so the two uses never share a word
+            // (an int column per thread, ints nthreads apart, would: entry 2j of thread 2B is entry j of thread B's).
             QStack st;
-            st.lds = (int)threadIdx.x; st.stride = RTX_BLOCK; st.spill = (int*)sc.spill + gtid; st.spillStride = nthreads; st.nsp = 0; st.nbase = 0; st.lsp = 0;
+            st.lds = (int)threadIdx.x; st.stride = RTX_BLOCK; st.spill = (int*)(sc.spill + gtid); st.spillStride = 2 * nthreads; st.nsp = 0; st.nbase = 0; st.lsp = 0;
             h = traverse_q<COUNT, MODE == RTX_MODE_WIDEQ_BIG>(sc, ox, oy, oz, dx, dy, dz, st, ic, lc);
         }
     } else if (clean) {

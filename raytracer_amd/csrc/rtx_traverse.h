@@ -397,7 +397,9 @@ __device__ __forceinline__ QRay q_ray(float ox, float oy, float oz, float ix, fl
     return r;
 }
 
+#ifndef RTX_QN             // (a power of two; tests build a variant with 2 so that small trees spill, tests/test_gpu_spill.py)
 #define RTX_QN 16          // node entries per lane kept in LDS (older ones spill to HBM; the stack is at most tree depth + 1 deep)
+#endif
 #define RTX_QL 4           // leaf entries per lane; a lane whose leaf stack is full takes no node step until it has room
 #define RTX_QWORDS (RTX_QN + RTX_QL)
 

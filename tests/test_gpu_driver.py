@@ -41,6 +41,31 @@ def test_headless_driver_renders_and_logs(tmp_path):
     assert np.abs(bgr[:, :, ::-1].astype(np.float32) - np.floor(want)).max() <= 1.0
 
 
+@pytest.mark.parametrize("name", ["scene1", "scene2"])
+def test_cxx_boundary_renders_the_oracles_image(tmp_path, name, request):
+    """The C++ face of the boundary against the oracle: rtx_run constructs rtxhost::HIPShader over a RenderingContext
+    (src/IFrameRender.h:6-9, src/ComputeShader.h:7-18) filled from the committed scene blob and runs the reference's
+    bounded loop — Render(pixels); frameCounter++ (src/Main.cpp:46-54, src/WindowManager.cpp:154-158) — for 4 frames;
+    the PFM it writes from `pixels` must hold the oracle's running mean bit for bit (RGB; a PFM has no alpha). Once
+    more as a device group of two members (RtxConfig.numDevices, -G 2), the route by which the reference's untouched
+    Main.cpp would drive several GPUs."""
+    import oracle
+    from conftest import GOLDEN, check_fb
+    s = request.getfixturevalue(name)
+    d, cam = s.desc(), s.camera
+    want = np.zeros((d.height, d.width, 4), np.float32)
+    for f in range(4):
+        oracle.render(d, cam, f, want, 8)
+    for extra in ([], ["-G", "2"]):
+        out = subprocess.run([RUN, "-L", os.path.join(GOLDEN, name + ".blob"), "-F", "4", "-o", "frame.pfm"] + extra,
+                             cwd=tmp_path, capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0, out.stderr
+        assert f"Resolution : {d.width} x {d.height}" in out.stdout
+        img = read_pfm(tmp_path / "frame.pfm")
+        check_fb(img, want[..., :3])
+        os.remove(tmp_path / "frame.pfm")
+
+
 def test_present_path_delivers_the_8bit_image(scene2):
     """rtx_present_rgba8: what WindowManager::UpdateWindow hands to the display (src/WindowManager.cpp:160-166, a GL_RGBA
     texture fed from the float pixels: clamp to [0,1], round to 8 bits), converted on the device."""

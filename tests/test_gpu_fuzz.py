@@ -1,18 +1,16 @@
 """Randomised parity: small synthetic scenes, random cameras, rays built to sit on the edges of the culled
 path's assumptions (signed zeros, denormal and huge reciprocals, origins on box planes). Bars as in
-test_gpu_parity.py: ids bit-exact, hit points and normals bit-exact, framebuffer within MAX_ABS / PSNR."""
+test_gpu_parity.py: ids bit-exact, hit points and normals bit-exact, framebuffer bit-identical (conftest.check_fb)."""
 import numpy as np
 import pytest
 
 import oracle
-from conftest import psnr
+from conftest import check_fb
 from raytracer_amd import _capi
 from raytracer_amd.renderer import HIPShader
 from raytracer_amd.scene import orbit, synthetic_scene
 
 pytestmark = pytest.mark.gpu
-MAX_ABS = 2e-3
-MIN_PSNR = 50.0
 
 
 @pytest.mark.parametrize("seed", range(6))
@@ -33,10 +31,7 @@ def test_random_scene_random_camera(libs, seed):
     px = r.download()
     # the reference's shading yields NaN for some grazing / back-side configurations (they then stay in the
     # running mean): the same pixels must be NaN here, and every other pixel within the tolerance
-    nan = np.isnan(want)
-    assert (np.isnan(px) == nan).all()
-    a, b = np.where(nan, 0.0, px), np.where(nan, 0.0, want)
-    assert float(np.abs(a - b).max()) <= MAX_ABS and psnr(a, b) >= MIN_PSNR
+    check_fb(px, want, nan_ok=True)
     r.close()
 
 

@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 
 import oracle
+from conftest import check_fb
 from raytracer_amd import _capi
 from raytracer_amd.renderer import HIPShader
 from raytracer_amd.scene import orbit
@@ -59,7 +60,7 @@ def test_group_matches_the_oracle(scene1):
         grp.frame_counter = f
         grp.Render(px)
         oracle.render(d, cam, f, want, 8)
-    assert float(np.abs(px - want).max()) <= 2e-3
+    check_fb(px, want)
     assert (grp.primary_hits(0) == oracle.primary_hits(d, cam, 0)).all()
     grp.close()
 

@@ -314,3 +314,73 @@ def test_render_is_independent_of_row_split(scene2):
     for y0 in range(0, d.height, 37):
         oracle.render(d, cam, 5, b, 3, rows=(y0, min(d.height, y0 + 37)))
     assert (bits(a) == bits(b)).all()
+
+
+@needs_ref
+def test_camera_look_at_rotate_and_orbit_basis_bit_exact():
+    """rtxh_camera_look_at / rtxh_camera_rotate / the basis rtxh_camera_orbit builds (what cfg5's orbit loop rests on)
+    against the reference's own Camera::LookAt / Camera::Rotate (src/Camera.h:26-55), compiled where it lies: all 96 bytes
+    of the camera, bit for bit. (The orbit POSITION formula lives in src/Main.cpp:68-77, which cannot be compiled here;
+    the basis for that position is Camera::LookAt's.)"""
+    H = _capi.host_lib()
+    r = np.random.default_rng(77)
+
+    def same(a, b):
+        # NaN lanes (looking straight up: normalize(0)) must be NaN in both; the sign / payload of a NaN is the compiler's choice
+        fa, fb = np.frombuffer(bytes(a), np.float32), np.frombuffer(bytes(b), np.float32)
+        na, nb = np.isnan(fa), np.isnan(fb)
+        return (na == nb).all() and (fa.view(np.uint32)[~na] == fb.view(np.uint32)[~nb]).all()
+
+    for trial in range(400):
+        cam = _capi.Camera()
+        cam.front = _capi.Vec4(0, 0, 1, 0); cam.up = _capi.Vec4(0, 1, 0, 0); cam.right = _capi.Vec4(1, 0, 0, 0)
+        cam.position = _capi.Vec4(*[float(np.float32(x)) for x in r.normal(size=3) * 2000], 0.0)
+        cam.movementSpeed, cam.rotationSpeed, cam.aspectRatio, cam.nearView, cam.farView, cam.fov = 500.0, float(np.float32(r.uniform(1, 200))), 1.0, 0.1, 100.0, 45.0
+        cam.pitch, cam.yaw = float(np.float32(r.uniform(-120, 120))), float(np.float32(r.uniform(-400, 400)))
+        tgt = (r.normal(size=3) * 500).astype(np.float32)
+        if trial % 50 == 0:
+            tgt = np.array([cam.position.x, cam.position.y + 10.0, cam.position.z], np.float32)     # looking straight up: worldUp x front = 0
+        a, b = _capi.Camera.from_buffer_copy(cam), _capi.Camera.from_buffer_copy(cam)
+        H.rtxh_camera_look_at(C.byref(a), tgt.ctypes.data_as(C.POINTER(C.c_float)))
+        ref.ref_camera_look_at(C.byref(b), tgt.ctypes.data)
+        assert same(a, b)
+        ox, oy = float(r.normal() * 0.3), float(r.normal() * 0.3)
+        H.rtxh_camera_rotate(C.byref(a), ox, oy)
+        ref.ref_camera_rotate(C.byref(b), ox, oy)
+        assert same(a, b)
+        # the orbit step: position from src/Main.cpp:68-77, then LookAt(0, 0, 0)
+        yaw, pitch = float(np.float32(0.1 * trial)), float(np.float32(0.1 * trial))
+        H.rtxh_camera_orbit(C.byref(a), yaw, pitch, 5000.0)
+        b.position = a.position
+        zero = np.zeros(3, np.float32)
+        ref.ref_camera_look_at(C.byref(b), zero.ctypes.data)
+        assert same(a, b)
+
+
+@needs_ref
+def test_bounding_box_layout_and_expand_match_the_reference():
+    """RtxBoundingBox (include/rtx.h) and the numpy mirror against the reference's own struct (src/BoundingBox.h:7-48):
+    size, alignment, offsets (also static_asserted in oracle/ref_parts.cpp), the default box (-1 ids, +-inf corners) and
+    Expand() — libm fmin / fmax, NaN rule included — against the box union our builders form."""
+    lay = np.zeros(8, np.int32)
+    ref.ref_box_layout(lay.ctypes.data)
+    B = _capi.BOX
+    assert list(lay) == [B.itemsize, B.fields["objectID"][1], B.fields["parentID"][1], B.fields["leftID"][1], B.fields["rightID"][1],
+                         B.fields["min"][1], B.fields["max"][1], 64]
+    r = np.random.default_rng(5)
+    for trial in range(200):
+        n = int(r.integers(0, 6))
+        boxes = np.zeros(max(n, 1), dtype=B)
+        lo = r.normal(size=(max(n, 1), 3)).astype(np.float32) * 100
+        hi = lo + r.random((max(n, 1), 3)).astype(np.float32) * 50
+        boxes["min"][:, :3] = lo; boxes["max"][:, :3] = hi
+        out = np.zeros(1, dtype=B)
+        area = ref.ref_box_expand(boxes.ctypes.data, n, out.ctypes.data)
+        assert out["objectID"][0] == -1 and out["leftID"][0] == -1 and out["rightID"][0] == -1
+        if n == 0:
+            assert np.isposinf(out["min"][0][:3]).all() and np.isneginf(out["max"][0][:3]).all()
+            continue
+        assert (bits(out["min"][0][:3]) == bits(lo[:n].min(axis=0))).all() and (bits(out["max"][0][:3]) == bits(hi[:n].max(axis=0))).all()
+        d = out["max"][0][:3] - out["min"][0][:3]
+        want = np.float32(2.0) * ((d[0] * d[1] + d[0] * d[2]) + d[1] * d[2])
+        assert np.float32(area).view(np.uint32) == np.float32(want).view(np.uint32)

@@ -12,6 +12,7 @@ from raytracer_amd.renderer import HIPShader
 
 pytestmark = pytest.mark.gpu
 MAX_RAYS = 1 << 19
+_CALLS = 0
 
 
 def _rays(n, seed):
@@ -33,8 +34,14 @@ def _noalloc(r, o, d):
     pts = torch.full((n, 4), -1.0, dtype=torch.float32, device="cuda")
     nrm = torch.full((n, 4), -1.0, dtype=torch.float32, device="cuda")
     torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]                  # hipMemGetInfo: free device memory
     rc = L.rtx_trace_rays_noalloc(r.handle, to.data_ptr(), td.data_ptr(), n, ids.data_ptr(), pts.data_ptr(), nrm.data_ptr())
+    free1 = torch.cuda.mem_get_info()[0]
     assert rc == 0, L.rtx_last_error().decode()
+    # the call allocates nothing on the device (the very first call of a process may still see the runtime's own lazy set-up)
+    global _CALLS
+    _CALLS += 1
+    assert free1 == free0 or _CALLS == 1, (free0, free1)
     return ids.cpu().numpy(), pts.cpu().numpy(), nrm.cpu().numpy()
 
 
@@ -44,7 +51,10 @@ def test_noalloc_entry_point_equals_the_allocating_one(synth_small, traversal):
     for n, seed in ((300_000, 1), (40_001, 2)):           # two calls in a row, the second with a smaller input
         o, d = _rays(n, seed)
         want_ids, want_pts, want_nrm = r.trace_rays(o, d)
+        c0 = r.counters()
         ids, pts, nrm = _noalloc(r, o, d)
+        c1 = r.counters()
+        assert c1.frames == c0.frames and list(c1.hitsPerBounce) == list(c0.hitsPerBounce)      # a probe, not a frame
         assert (want_ids >= 0).sum() > n // 20
         assert (ids == want_ids).all()
         assert (pts.view(np.uint32) == want_pts.view(np.uint32)).all()
