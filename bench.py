@@ -4,6 +4,8 @@
     python bench.py --gpus 1 --steps 5 --warmup 2
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N                  (no launcher around it: starts the line above as a child process itself)
+    python bench.py --gpus N --mode group     (ONE process, N GPUs behind one handle: RtxConfig.numDevices)
 
 A step = one frame = one sample per pixel over the whole image (the reference's
 "N spp" is N accumulated frames). Default workload = BASELINE.json
@@ -99,9 +101,38 @@ def sync_only(args):
     print(json.dumps(out))
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: become N ranks. The launcher is started as a CHILD
+    process, before this process has imported torch or touched the GPU in any way (never an exec of a process that has),
+    with the command line the driver documents; rank 0's JSON line is relayed, the exit code is the launcher's."""
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for line in proc.stdout:
+        if line.startswith("{"):
+            try:
+                out = json.loads(line)
+                out.setdefault("config", {})["launched_by"] = "bench.py itself: child `python -m torch.distributed.run --nproc-per-node N` (WORLD_SIZE was unset)"
+                line = json.dumps(out) + "\n"
+            except ValueError:
+                pass
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    raise SystemExit(proc.wait())
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--mode", default="ranks", choices=["ranks", "group"],
+                    help="how N > 1 GPUs are driven: ranks = one process per GPU, tiles gathered over torch.distributed (RCCL); "
+                         "group = ONE process, a device group behind one handle (RtxConfig.numDevices), tiles gathered by peer copies")
     ap.add_argument("--steps", type=int, default=64)
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--workload", default="cfg4_10Mtri_4k", choices=sorted(WORKLOADS))
@@ -118,11 +149,13 @@ def main():
     args = ap.parse_args()
     if args.sync_only:
         return sync_only(args)
+    if args.gpus > 1 and args.mode == "ranks" and "WORLD_SIZE" not in os.environ:
+        return self_launch(args)
 
     # One GPU: HIP's defaults (4 hardware queues per process; batches of 8 frames, 3 in flight need no more — measured equal
     # with 16). Ranks of a multi-GPU run keep up to 14 shorter batches in flight, one stream each: they get a hardware
     # queue per stream (HIP reads this once, when the process first touches the GPU).
-    if int(os.environ.get("WORLD_SIZE", "1")) > 1 and int(os.environ.get("GPU_MAX_HW_QUEUES", "4")) < 16:
+    if (int(os.environ.get("WORLD_SIZE", "1")) > 1 or (args.mode == "group" and args.gpus > 1)) and int(os.environ.get("GPU_MAX_HW_QUEUES", "4")) < 16:
         os.environ["GPU_MAX_HW_QUEUES"] = "16"
 
     rank = int(os.environ.get("RANK", "0"))
@@ -130,6 +163,9 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    group_n = args.gpus if (args.mode == "group" and args.gpus > 1) else 0
+    if group_n and world > 1:
+        raise SystemExit("--mode group is one process: do not start it under torch.distributed.run")
 
     import torch
     import torch.distributed as dist
@@ -164,8 +200,14 @@ def main():
     modes = {"wide": _capi.TRAVERSE_WIDE, "culled": _capi.TRAVERSE_CULLED, "exact": _capi.TRAVERSE_EXACT}
     trav = modes[args.traversal]
     t0 = time.time()
-    shader = HIPShader(scene, device=local_rank, rank=rank, world_size=world, traversal=trav,
-                       frames_in_flight=args.frames_in_flight)
+    group_devices = None
+    if group_n:
+        present = max(1, torch.cuda.device_count())
+        group_devices = [i % present for i in range(group_n)]          # fewer GPUs than members: rehearsal, members share devices
+        shader = HIPShader(scene, devices=group_devices, traversal=trav, frames_in_flight=args.frames_in_flight)
+    else:
+        shader = HIPShader(scene, device=local_rank, rank=rank, world_size=world, traversal=trav,
+                           frames_in_flight=args.frames_in_flight)
     t_create = time.time() - t0
     info = shader.info()
     W, H = shader.width, shader.height
@@ -213,7 +255,12 @@ def main():
     rays_local = float(c.rays)
     t = torch.tensor([elapsed], dtype=torch.float64, device=red_device)
     rsum = torch.tensor([rays_local], dtype=torch.float64, device=red_device)
+    per_rank = [{"rank": 0, "rays": int(rays_local), "ms": elapsed * 1e3, "device_ms": c.totalMs}]
     if use_dist:
+        mine = torch.tensor([rays_local, elapsed * 1e3, c.totalMs], dtype=torch.float64, device=red_device)
+        everyone = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+        dist.all_gather(everyone, mine)
+        per_rank = [{"rank": k, "rays": int(v[0].item()), "ms": float(v[1].item()), "device_ms": float(v[2].item())} for k, v in enumerate(everyone)]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(rsum, op=dist.ReduceOp.SUM)
     elapsed = float(t.item())
@@ -327,7 +374,7 @@ def main():
 
     # ---- the same frames with distance culling (opt-in mode; not exact by construction) ---------------------------
     culled = None
-    if rank == 0 and world == 1 and args.traversal == "wide" and not args.no_extras:
+    if rank == 0 and world == 1 and not group_n and args.traversal == "wide" and not args.no_extras:
         other = HIPShader(scene, device=local_rank, traversal=_capi.TRAVERSE_CULLED, frames_in_flight=args.frames_in_flight)
         for i in range(args.warmup):
             step(other, i)
@@ -345,7 +392,7 @@ def main():
 
     # ---- the reference's calling pattern, default hardware queues, in a process of its own ----------------------
     sync = None
-    if rank == 0 and world == 1 and not args.no_extras and not args.orbit:
+    if rank == 0 and world == 1 and not group_n and not args.no_extras and not args.orbit:
         env = dict(os.environ)
         env.pop("GPU_MAX_HW_QUEUES", None)
         try:
@@ -358,7 +405,7 @@ def main():
 
     # ---- CPU baseline: the oracle (CPU restatement of ThreadedShader) on a bounded sample ----
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not group_n and not args.no_cpu_baseline:
         import oracle
         desc = scene.desc()
         fc = args.warmup
@@ -385,14 +432,22 @@ def main():
                             "sample": samplef + "; the same source with the reference's shipped flags (-Ofast, CMakeLists.txt:11)"}
 
     if rank == 0:
-        out = {"metric": "Mrays/s", "value": rays / elapsed / 1e6, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
+        if group_n:
+            collective = {"kind": "one process, device group: hipMemcpyPeerAsync fan-in to devices[0] (no process group)", "members": group_n,
+                          "devices": group_devices, "gpus_present": torch.cuda.device_count(), "rays_all_members": int(rays_local)}
+        elif use_dist:
+            collective = {"kind": "torch.distributed.gather to rank 0", "backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                          "gpus_present": torch.cuda.device_count(), "per_rank": per_rank, "rays_sum_over_ranks": int(rays)}
+        else:
+            collective = None
+        out = {"metric": "Mrays/s", "value": rays / elapsed / 1e6, "unit": "Mrays/s", "n_gpus": group_n if group_n else world, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
                "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": args.workload, "triangles": ntri, "resolution": [W, H], "bounces": 4,
                           "spp_per_step": 1, "traversal": args.traversal, "traversal_in_effect": {v: k for k, v in modes.items()}[info.traversal],
                           "exact_by_construction": args.traversal != "culled",
-                          "partition": f"tiles64x32 round-robin x{world}",
-                          "camera": "orbit" if args.orbit else "fixed", "collective": backend if use_dist else None,
+                          "partition": f"tiles64x32 round-robin x{group_n if group_n else world}", "mode": args.mode if (group_n or world > 1) else "single",
+                          "camera": "orbit" if args.orbit else "fixed", "collective": collective,
                           "timed_region": "K x rtx_render(pixels=NULL) + tile gather to rank 0 + one device-to-host copy of the frame",
                           "frames_in_flight": info.framesInFlight, "frames_per_batch": info.framesPerBatch,
                           "GPU_MAX_HW_QUEUES": info.hwQueues},

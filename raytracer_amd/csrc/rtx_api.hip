@@ -842,14 +842,45 @@ int rtx_create(const RtxSceneDesc* scene, const RtxConfig* cfgIn, RtxRenderer** 
     // Device group (single process, several GPUs): member i renders the tiles of rank i of numDevices on devices[i],
     // all from the one flattened scene; member 0 is the handle the caller gets, and delivering a frame gathers the
     // other members' tiles into its framebuffer (gather_group).
-    std::vector<RtxRenderer*> members;
-    for (int i = 0; i < cfg.numDevices; ++i) {
-        RtxConfig c = cfg;
-        c.device = cfg.devices[i]; c.rank = i; c.worldSize = cfg.numDevices; c.numDevices = -1;      // -1: a member of a device group
-        RtxRenderer* m = nullptr;
-        if (build_renderer(scene, c, flat, useBVH, createClock, &raw, &m)) { for (RtxRenderer* x : members) rtx_destroy(x); return 1; }
-        members.push_back(m);
+    // The members are built side by side, one host thread per member (uploads, record emission and allocations of
+    // different devices do not wait for each other); only member 0 consumes the raw arrays that started crossing PCIe
+    // before the flatten. Links first: the gather is one peer copy per member into devices[0].
+    for (int i = 1; i < cfg.numDevices; ++i) {
+        if (cfg.devices[i] == cfg.devices[0]) continue;                // rehearsal: several members on one GPU
+        int can = 0;
+        HIP_TRY(hipDeviceCanAccessPeer(&can, cfg.devices[0], cfg.devices[i]));
+        if (!can && !getenv("RTX_GROUP_STAGED"))
+            return fail("device group: device " + std::to_string(cfg.devices[0]) + " cannot access device " + std::to_string(cfg.devices[i]) +
+                        " as a peer (no xGMI / PCIe P2P path: check `rocm-smi --showtopo`, IOMMU / ACS settings and HSA_ENABLE_IPC_MODE_LEGACY=0); "
+                        "set RTX_GROUP_STAGED=1 to gather through host memory anyway, or run one process per GPU (RtxConfig.rank / worldSize)");
+        if (can) {
+            HIP_TRY(hipSetDevice(cfg.devices[0]));
+            const hipError_t pe = hipDeviceEnablePeerAccess(cfg.devices[i], 0);
+            if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) return fail(std::string("hipDeviceEnablePeerAccess: ") + hipGetErrorString(pe));
+            (void)hipGetLastError();
+        }
     }
+    std::vector<RtxRenderer*> members((size_t)cfg.numDevices, nullptr);
+    std::vector<std::string> errors((size_t)cfg.numDevices);
+    {
+        std::vector<std::thread> pool;
+        auto buildOne = [&](int i) {
+            RtxConfig c = cfg;
+            c.device = cfg.devices[i]; c.rank = i; c.worldSize = cfg.numDevices; c.numDevices = -1;      // -1: a member of a device group
+            PhaseClock clock = createClock;
+            if (build_renderer(scene, c, flat, useBVH, clock, i == 0 ? &raw : nullptr, &members[(size_t)i])) { errors[(size_t)i] = g_err; members[(size_t)i] = nullptr; }
+        };
+        const bool serial = getenv("RTX_GROUP_SERIAL_CREATE") != nullptr;
+        for (int i = 1; i < cfg.numDevices; ++i) { if (serial) buildOne(i); else pool.emplace_back(buildOne, i); }
+        buildOne(0);
+        for (auto& th : pool) th.join();
+    }
+    for (int i = 0; i < cfg.numDevices; ++i)
+        if (!members[(size_t)i]) {
+            const std::string msg = "device group member " + std::to_string(i) + " (device " + std::to_string(cfg.devices[i]) + "): " + errors[(size_t)i];
+            for (RtxRenderer* x : members) if (x) rtx_destroy(x);
+            return fail(msg);
+        }
     RtxRenderer* lead = members[0];
     lead->peers.assign(members.begin() + 1, members.end());
     lead->info.devices = cfg.numDevices;

@@ -161,7 +161,7 @@ def test_cfg5_orbit_camera_over_a_replicated_mesh_4k(libs, monkeypatch, ORBIT_TR
     if ORBIT_TRIS < 80_000_000:
         monkeypatch.setenv("RTX_FORCE_BIG", "1")
     cam = s.camera
-    frames = 12
+    frames = 12 if ORBIT_TRIS <= 10_000_000 else 5
     out = {}
     for name in ("wide", "culled"):
         r = HIPShader(s, traversal=MODES[name])
@@ -184,9 +184,14 @@ def test_cfg5_orbit_camera_over_a_replicated_mesh_4k(libs, monkeypatch, ORBIT_TR
     assert (out["wide"][1].view(np.uint32) == out["culled"][1].view(np.uint32)).all()
     ids, fb = out["wide"]
     assert (ids >= 0).mean() > 0.2                       # the orbit really looks at the geometry
+    # frameCounter = 0 gives a Lerp scale of 1, but old + (new - old) * 1 equals the new colour only up to a rounding
+    # (src/ThreadedShader.cpp:179-180): the oracle replays the whole orbit on the band of rows it is compared on
     y0, y1 = 1100, 1132
     want = np.zeros_like(fb)
-    oracle.render(d, cam, 0, want, 16, rows=(y0, y1))
+    ocam = s.camera
+    for i in range(frames):
+        orbit(ocam, 200.0 + 0.1 * i, 0.1 * i)
+        oracle.render(d, ocam, 0, want, 16, rows=(y0, y1))
     check_fb(fb[y0:y1], want[y0:y1])
     # primary ids: the whole frame at 10 M; at 100 M (the CPU walks ~140 boxes per ray there) the rows of the band
     if ORBIT_TRIS <= 10_000_000:

@@ -125,9 +125,11 @@ def test_moving_camera(scene1):
     r = HIPShader(scene1)
     cam = scene1.camera
     px = np.zeros((d.height, d.width, 4), np.float32)
+    # `pixels` persists across the frames (src/ThreadedShader.cpp:179-180): with frameCounter = 0 the Lerp scale is 1, and
+    # old + (new - old) * 1 is the new colour only up to a rounding — so the oracle carries its image along as well
+    want = np.zeros_like(px)
     for i in range(3):
         orbit(cam, 40.0 * i + 10, 5.0 * i, radius=2500.0)
-        want = np.zeros_like(px)
         r.frame_counter = 0
         r.Render(px, cam)
         oracle.render(d, cam, 0, want, 8)
