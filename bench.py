@@ -122,7 +122,7 @@ def self_launch(args):
                 line = json.dumps(out) + "\n"
             except ValueError:
                 pass
-        sys.stdout.write(line)
+        (sys.stdout if line.startswith("{") else sys.stderr).write(line)      # stdout carries the JSON line only
         sys.stdout.flush()
     raise SystemExit(proc.wait())
 

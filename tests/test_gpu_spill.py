@@ -17,6 +17,6 @@ def test_spill_columns_of_clean_and_axis_parallel_lanes_never_overlap():
     if not os.path.exists(lib):
         pytest.fail("raytracer_amd/librtx_hip_qn2.so is not built (make -C raytracer_amd/csrc all)")
     env = dict(os.environ, RTX_HIP_LIB="librtx_hip_qn2.so")
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "spill_check.py")], env=env, capture_output=True, text=True, timeout=300)
+    out = subprocess.run([sys.executable, "-u", "-X", "faulthandler", os.path.join(ROOT, "tests", "spill_check.py")], env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert "spill check OK" in out.stdout
