@@ -746,7 +746,8 @@ inline bool quantize4(const Raw<Node4>& in, Raw<NodeQ>& out, std::vector<uint32_
                 for (int j = 0; j < nc; ++j) { lo = std::min(lo, q[8 * a + p.slot[j]]); hi = std::max(hi, q[8 * a + 4 + p.slot[j]]); }
                 if (nc == 0) { lo = 0.0f; hi = 0.0f; }
                 const double ext = (double)hi - (double)lo;
-                if (!std::isfinite(ext) || !std::isfinite(lo) || ext < 0.0) { bad[(size_t)t] = 1; lo = 0.0f; hi = 0.0f; }
+                // (coordinates beyond +-2^40: the folded inner test of the walk is proven overflow-free only inside that range, rtx_traverse.h)
+                if (!std::isfinite(ext) || !std::isfinite(lo) || ext < 0.0 || std::fabs(lo) > 1.099511627776e12f || std::fabs(hi) > 1.099511627776e12f) { bad[(size_t)t] = 1; lo = 0.0f; hi = 0.0f; }
                 int eb = 1;                                           // biased exponent of the grid step, 1..254
                 if (ext > 0.0 && std::isfinite(ext)) { int ex; std::frexp(ext / 255.0, &ex); eb = std::min(254, std::max(1, ex + 127)); }   // 2^ex >= ext / 255
                 uint32_t wl = 0, wh = 0;

@@ -132,7 +132,7 @@ __device__ __forceinline__ Hit closest_hit(const DevScene& sc, float ox, float o
     // own tree: clean lanes take the fast path; a lane whose slab test could produce NaN (axis-parallel
     // direction, non-finite input) walks the reference topology with the reference's exact semantics
     Hit h; h.t = INFINITY; h.leaf = -1; h.box = -1;
-    const bool clean = lane_is_clean(ox, oy, oz, dx, dy, dz);
+    const bool clean = (MODE == RTX_MODE_WIDEQ || MODE == RTX_MODE_WIDEQ_BIG) ? q_lane_ok(ox, oy, oz, dx, dy, dz) : lane_is_clean(ox, oy, oz, dx, dy, dz);
     const long long nthreads = (long long)gridDim.x * RTX_BLOCK;
     const long long gtid = (long long)blockIdx.x * RTX_BLOCK + threadIdx.x;
     if (MODE == RTX_MODE_WIDEQ || MODE == RTX_MODE_WIDEQ_BIG) {
@@ -466,7 +466,7 @@ __global__ __launch_bounds__(RTX_BLOCK) RTX_TRACEQ_ATTR void k_trace_q(DevScene 
                 const uint32_t qn = mine ? rcur + rank : rcur;
                 const float4 o = rqO[qn], d = rqD[qn];
                 const bool hole = d.w != 0.0f;             // slot outside the image, or a hole in a bounce queue
-                const bool clean = lane_is_clean(o.x, o.y, o.z, d.x, d.y, d.z);
+                const bool clean = q_lane_ok(o.x, o.y, o.z, d.x, d.y, d.z);
                 const QRay nr = q_ray(o.x, o.y, o.z, 1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
                 const bool start = mine && !hole && clean;
                 q = mine ? qn : q;
@@ -474,6 +474,9 @@ __global__ __launch_bounds__(RTX_BLOCK) RTX_TRACEQ_ATTR void k_trace_q(DevScene 
                 r.ox = start ? nr.ox : r.ox; r.oy = start ? nr.oy : r.oy; r.oz = start ? nr.oz : r.oz;
                 r.ix = start ? nr.ix : r.ix; r.iy = start ? nr.iy : r.iy; r.iz = start ? nr.iz : r.iz;
                 r.nx = start ? nr.nx : r.nx; r.ny = start ? nr.ny : r.ny; r.nz = start ? nr.nz : r.nz;
+#if RTX_QFAST
+                r.ex = start ? nr.ex : r.ex; r.ey = start ? nr.ey : r.ey; r.ez = start ? nr.ez : r.ez;
+#endif
                 best.t = start ? INFINITY : best.t; best.leaf = start ? -1 : best.leaf; best.box = start ? -1 : best.box;
                 st.nsp = start ? 0 : st.nsp; st.nbase = start ? 0 : st.nbase; st.lsp = start ? 0 : st.lsp;
                 nodeCur = start ? RTX_QENTRY(0, 1) : nodeCur; leafCur = start ? 0 : leafCur;

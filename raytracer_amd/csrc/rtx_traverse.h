@@ -390,11 +390,48 @@ __device__ __forceinline__ Hit traverse_fast(const DevScene& sc, float ox, float
 // are ONE entry, its passing leaf children another. Every pass a lane takes one node step and one leaf test, whichever
 // of the two it has, so the two sections of a pass run on well-filled waves and a ray needs about max(node steps,
 // leaf tests) passes instead of their interleaved sum.
-struct QRay { float ox, oy, oz, ix, iy, iz; bool nx, ny, nz; };   // n*: the reciprocal is negative, the near plane is hi
+#ifndef RTX_QFAST
+#define RTX_QFAST 1        // 1: inner tests in the folded form with a proven error margin (q_step); 0: the reference's own form on the decoded planes
+#endif
+// The folded inner test (RTX_QFAST). An inner test only has to be CONSERVATIVE (pass whenever the exact test of a leaf below
+// passes; the leaf's own exact box, tested with the reference's arithmetic in q_leaf, has the last word — DESIGN.md 3.1).
+// The reference form at a decoded plane p_f = fl(org + b*s) is G = fl(fl(p_f - o) * inv): cvt, fma, sub, mul per plane.
+// Folded: per node and axis S = s * inv (exact: s is a power of two), A = fl(fl(org - o) * inv), and per plane
+// H = fl(b * S + A): cvt + fma. With T = (org + b*s - o) * inv in real arithmetic and u = 2^-24 (no overflow, see below):
+//     |G - T| <= 1.001 u |inv| (|org| + 255 s) + 2.001 u |T|          (rounding of p_f, of the difference, of the product)
+//     |H - T| <= 2.002 u |A| + u |T|                                   (two roundings of A, one of the fma)
+//     |T| <= |A| + 255 |S|,   |org * inv| <= |A| (1 + 2.01 u) + |o * inv|
+// hence |H - G| <= u (6.01 |A| + 1022 |S| + 1.01 |o * inv|) =: d. The test uses A - 2d for the entry planes and A + 2d for
+// the exit planes (the factor 2 covers the roundings of d itself and of A -+ 2d, plus 2^-120 for results that round in the
+// subnormal range), so Hn <= G(near plane) and Hf >= G(far plane) per axis: max Hn <= max Gn <= min Gf <= min Hf and
+// min Hf >= min Gf > 0 whenever the reference-form test of the decoded box passes — which it does whenever a leaf below
+// passes (monotonic rounding). False positives cost a node step, never a hit.
+// No overflow: lanes take this walk only when |inv| <= 2^40 and |o| <= 2^40 (q_lane_ok; others go to the reference-topology
+// side kernel), and rtx_create quantises only scenes whose boxes lie within +-2^40 (|A| <= 2^82, |S| <= 2^76).
+#define RTX_Q_RANGE 1.099511627776e12f      // 2^40
+struct QRay { float ox, oy, oz, ix, iy, iz; bool nx, ny, nz;      // n*: the reciprocal is negative, the near plane is hi
+#if RTX_QFAST
+              float ex, ey, ez;                                   // 2^-23 * 1.01 |o * inv| + 2^-120: the ray's share of the margin 2d
+#endif
+};
 __device__ __forceinline__ QRay q_ray(float ox, float oy, float oz, float ix, float iy, float iz) {
     QRay r; r.ox = ox; r.oy = oy; r.oz = oz; r.ix = ix; r.iy = iy; r.iz = iz;
     r.nx = ix < 0.0f; r.ny = iy < 0.0f; r.nz = iz < 0.0f;
+#if RTX_QFAST
+    const float k = 1.2040138e-7f /* 1.01 * 2^-23 */, tiny = 7.5231638e-37f /* 2^-120 */;
+    r.ex = fmaf(k, fabsf(ox * ix), tiny); r.ey = fmaf(k, fabsf(oy * iy), tiny); r.ez = fmaf(k, fabsf(oz * iz), tiny);
+#endif
     return r;
+}
+// A lane walks the quantised tree only when its slab arithmetic cannot produce NaN (lane_is_clean) and, with the folded
+// inner test, cannot overflow either.
+__device__ __forceinline__ bool q_lane_ok(float ox, float oy, float oz, float dx, float dy, float dz) {
+    bool ok = lane_is_clean(ox, oy, oz, dx, dy, dz);
+#if RTX_QFAST
+    ok = ok && fabsf(1.0f / dx) <= RTX_Q_RANGE && fabsf(1.0f / dy) <= RTX_Q_RANGE && fabsf(1.0f / dz) <= RTX_Q_RANGE &&
+         fabsf(ox) <= RTX_Q_RANGE && fabsf(oy) <= RTX_Q_RANGE && fabsf(oz) <= RTX_Q_RANGE;
+#endif
+    return ok;
 }
 
 #ifndef RTX_QN             // (a power of two; tests build a variant with 2 so that small trees spill, tests/test_gpu_spill.py)
@@ -456,6 +493,24 @@ __device__ __forceinline__ uint32_t q_step(const QNodeData& n, const QRay& r, in
     const uint32_t nzw = r.nz ? c.y : c.x, fzw = r.nz ? c.x : c.y;
     baseInner = (int)c.z; baseLeaf = (int)c.w; leafBits = meta >> 28;
     uint32_t mask = 0;
+#if RTX_QFAST
+    // folded form with margin (see QRay): per axis S, A -+ 2d; per plane one conversion and one fma
+    const float Sx = sx * r.ix, Sy = sy * r.iy, Sz = sz * r.iz;
+    const float Ax = (orx - r.ox) * r.ix, Ay = (ory - r.oy) * r.iy, Az = (orz - r.oz) * r.iz;
+    const float kA = 7.1644784e-7f /* 6.01 * 2^-23 */, kS = 1.2183190e-4f /* 1022 * 2^-23 */;
+    const float mx = fmaf(kA, fabsf(Ax), fmaf(kS, fabsf(Sx), r.ex)), my = fmaf(kA, fabsf(Ay), fmaf(kS, fabsf(Sy), r.ey)), mz = fmaf(kA, fabsf(Az), fmaf(kS, fabsf(Sz), r.ez));
+    const float Anx = Ax - mx, Any = Ay - my, Anz = Az - mz, Afx = Ax + mx, Afy = Ay + my, Afz = Az + mz;
+#define RTX_QBYTE(word, k) ((float)(((word) >> (8 * (k))) & 0xffu))
+#define RTX_QCHILD(k) {                                                                                                      \
+        const float tn = fmaxf(fmaf(RTX_QBYTE(nxw, k), Sx, Anx), fmaxf(fmaf(RTX_QBYTE(nyw, k), Sy, Any), fmaf(RTX_QBYTE(nzw, k), Sz, Anz))); \
+        const float tf = fminf(fmaf(RTX_QBYTE(fxw, k), Sx, Afx), fminf(fmaf(RTX_QBYTE(fyw, k), Sy, Afy), fmaf(RTX_QBYTE(fzw, k), Sz, Afz))); \
+        mask |= (tn <= tf && tf > 0.0f) ? (1u << (k)) : 0u; }
+    RTX_QCHILD(0) RTX_QCHILD(1) RTX_QCHILD(2) RTX_QCHILD(3)
+#undef RTX_QCHILD
+#undef RTX_QBYTE
+    (void)sx; (void)sy; (void)sz;
+    return mask & ((meta >> 24) & 15u);
+#endif
     // decoded plane = fma(byte, step, origin) (the value rtx_build.h verified against the child's box), then the
     // reference's own (p - o) * inv: separate subtraction and multiplication. (Written for pairs of children as packed
     // FP32 — v_pk_fma / v_pk_add / v_pk_mul — the step needs 108 registers instead of 77, occupancy falls from 6 to 4

@@ -137,12 +137,23 @@ int main() {
     check_quantised(none, 0, 1);
     {   // extreme coordinates: a huge box next to a tiny one far from the origin, and an infinite extent (must be refused)
         std::vector<Box> prim(3);
-        const float v[3][2] = {{-3.0e37f, 3.0e37f}, {1.0e6f, 1.0e6f + 0.125f}, {-1.0e-30f, 1.0e-30f}};
+        // (+-2^40 is the range rtx_create quantises: the walk's folded inner test is proven overflow-free inside it)
+        const float v[3][2] = {{-1.0e12f, 1.0e12f}, {1.0e6f, 1.0e6f + 0.125f}, {-1.0e-30f, 1.0e-30f}};
         for (int i = 0; i < 3; ++i) for (int a = 0; a < 3; ++a) { prim[i].lo[a] = v[i][0]; prim[i].hi[a] = v[i][1]; }
         std::vector<uint32_t> order{0, 1, 2}; std::vector<Node> bin(2); int d = 0;
         const int32_t root = build_sah(prim.data(), 3, order.data(), bin.data(), 1, d);
         Raw<Node4> wide; int d4 = 0; collapse4(bin.data(), bin.size(), root, wide, d4, 1);
-        check_quantised(wide, 3, 1, 1e33f);
+        check_quantised(wide, 3, 1, 1e9f);
+        {   // beyond the range: refused (the caller keeps the float nodes)
+            std::vector<Box> far(prim); far[0].lo[2] = -3.0e37f; far[0].hi[2] = 3.0e37f;
+            std::vector<uint32_t> o2{0, 1, 2}; std::vector<Node> b2(2); int dd = 0, dd4 = 0;
+            const int32_t r2 = build_sah(far.data(), 3, o2.data(), b2.data(), 1, dd);
+            Raw<Node4> w2; collapse4(b2.data(), b2.size(), r2, w2, dd4, 1);
+            Raw<NodeQ> q2; std::vector<uint32_t> n2;
+            CHECK(!quantize4(w2, q2, n2, 1));
+        }
+        CHECK(q_entry_base(q_entry(kQuantMaxLeaves + 3, 15)) == kQuantMaxLeaves + 3 && q_entry_base(q_entry(-4, 15)) == -4 && (q_entry(-4, 15) & 15) == 15);
+        CHECK(q_entry_base(q_entry(1 << 27, 1)) != (1 << 27));      // where the encoding wraps: kQuantMaxLeaves stays below it
         prim[0].hi[1] = INFINITY;
         order = {0, 1, 2};
         const int32_t root2 = build_sah(prim.data(), 3, order.data(), bin.data(), 1, d);
