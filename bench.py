@@ -78,19 +78,20 @@ def sync_only(args):
     for key, look in (("no_look_ahead", -1), ("default", 0)):
         shader = HIPShader(scene, device=0, traversal=trav, look_ahead=look)
         px = np.zeros((shader.height, shader.width, 4), dtype=np.float32)
-        for i in range(3):
+        warm = 12                               # the loop is recognised after two frames; the sets started ahead grow over the next few
+        for i in range(warm):
             shader.frame_counter = i
             shader.Render(px)
-        c0 = shader.counters()                  # (no reset here: it would make the renderer forget the loop it has seen)
-        n = max(4, min(args.steps, 32))
+        # (no counters() / reset here: they would make the renderer forget the loop it has seen; rays are taken from a frame count)
+        n = int(os.environ.get("RTX_SYNC_FRAMES", max(16, min(args.steps, 64))))
         t0 = time.perf_counter()
         for i in range(n):
-            shader.frame_counter = 3 + i            # src/WindowManager.cpp:156-157
+            shader.frame_counter = warm + i         # src/WindowManager.cpp:156-157
             shader.Render(px)
         dt = time.perf_counter() - t0
         c = shader.counters()
         info = shader.info()
-        res[key] = {"ms_per_step": dt / n * 1e3, "mrays_per_s": float(c.rays - c0.rays) / dt / 1e6, "frames": n, "look_ahead": info.lookAhead,
+        res[key] = {"ms_per_step": dt / n * 1e3, "mrays_per_s": float(c.rays) * n / (warm + n) / dt / 1e6, "frames": n, "look_ahead": info.lookAhead,
                     "hw_queues_seen": info.hwQueues}
         shader.close()
     out = dict(res["default"])

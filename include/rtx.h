@@ -161,11 +161,14 @@ typedef struct RtxConfig {
     int32_t lookAhead;     /* rtx_render WITH pixels hands the frame back before it returns, so calls cannot overlap —
                               unless the renderer starts the next frames before they are asked for. After two calls in
                               a row for (camera, n) and (camera, n + 1) — the reference's loop, src/WindowManager.cpp:
-                              154-158 — it queues up to `lookAhead` following frames (everything but their update of the
-                              running mean) before it copies the current one out; the next call either asks for the
-                              first of them or they are dropped unused. Results and counters are the same either way;
-                              a wrong guess costs device time only. 0 -> up to 3, at most framesInFlight - 1 (2 with
-                              HIP's default 4 hardware queues); -1 -> never. A device group looks ahead on all its members. */
+                              154-158 — it starts up to `lookAhead` SETS of following frames (everything but their update of
+                              the running mean) before it copies the current one out; a set is one set of launches for 1, 2,
+                              then 4 consecutive frames (it grows while the loop lasts, so that a short loop or an early
+                              wrong guess wastes little), applied to the running mean one frame per call. The next call
+                              either asks for the first frame started ahead or they are all dropped unused. Images and work
+                              counters are the same either way; a wrong guess costs device time only (at most ~3 sets).
+                              0 -> up to 3, at most framesInFlight - 1 (2 with HIP's default 4 hardware queues); -1 -> never.
+                              A device group looks ahead on all its members. */
     int32_t framesPerBatch;/* frames queued with pixels_rgba == NULL are collected and rendered `framesPerBatch` at a time by
                               one set of launches (longer queues: the thin ends of the launches are shared by the frames of a
                               batch); any call that needs results renders what has been collected first, so results do not

@@ -155,12 +155,14 @@ struct RtxRenderer {
     // resolve, with work counters of their own. The next rtx_render either asks for exactly the oldest of them (its resolve
     // is queued, its counters are added, and the look-ahead is topped up at the next delivery) or for something else (they
     // are dropped: their launches run out unused, nothing they wrote is ever read). Every other entry point drops them too.
-    struct Ahead { RtxCamera cam{}; uint32_t fc = 0; int ctx = -1; DevBatch bt{}; int ringSlot = -1; };
+    struct Ahead { RtxCamera cam{}; uint32_t fc = 0; int ctx = -1; DevBatch bt{}; int ringSlot = -1; int index = 0; };   // frame `index` of the batch `bt` started on context `ctx`
     std::deque<Ahead> ahead;            // frames started ahead, oldest first: consecutive frame counters, one camera
     bool haveLast = false; RtxCamera lastCam{}; uint32_t lastFc = 0;      // the last frame asked for
     int streak = 0;                     // calls in a row that asked for (same camera, frame counter + 1)
     int rendersSinceDelivery = 0;       // the loop is: one frame, one delivery
-    int lookAhead = 0;                  // how many frames are started ahead (0: never)
+    int lookAhead = 0;                  // how many sets of launches are started ahead (0: never)
+    int aheadBatch = 1;                 // most frames per set started ahead (1 with countStats: visit counters are per set)
+    int aheadNext = 1;                  // frames of the next set: 1 when a loop is recognised, doubling with every set started while it lasts
 };
 
 // ---------------------------------------------------------------------------------
@@ -1052,7 +1054,7 @@ static int build_renderer(const RtxSceneDesc* scene, const RtxConfig& cfg, const
         CREATE_HIP(hipMalloc((void**)&c.dAcc, n * sizeof(float4)));
         CREATE_HIP(hipMalloc((void**)&c.dSeeds, n * sizeof(uint32_t)));
         CREATE_HIP(hipMalloc((void**)&c.dCtrl, RTX_CTRL_WORDS * sizeof(uint32_t)));
-        CREATE_HIP(hipMalloc((void**)&c.dStatsAhead, RTX_STAT_WORDS * sizeof(unsigned long long)));
+        CREATE_HIP(hipMalloc((void**)&c.dStatsAhead, (size_t)RTX_MAX_BATCH * RTX_STAT_WORDS * sizeof(unsigned long long)));
         if (culled) {
             CREATE_HIP(hipMalloc((void**)&c.dSlow, nq * sizeof(uint32_t)));
             CREATE_HIP(hipMalloc((void**)&c.dSpill, (size_t)r->sc.stackDepth * r->gridTrace * RTX_BLOCK * sizeof(int2)));
@@ -1060,6 +1062,8 @@ static int build_renderer(const RtxSceneDesc* scene, const RtxConfig& cfg, const
     }
     r->lookAhead = cfg.lookAhead < 0 ? 0 : std::min(cfg.lookAhead > 0 ? cfg.lookAhead : 3, depth - 1);       // 2 with HIP's default 4 hardware queues (3 contexts)
     if (const char* e = getenv("RTX_LOOKAHEAD")) r->lookAhead = std::max(0, std::min(atoi(e), depth - 1));
+    r->aheadBatch = cfg.countStats ? 1 : std::min(r->batch, 4);      // (measured over 256 delivered 4K frames: 7.44 / 6.81 / 6.72 / 6.65 ms per frame with sets of 1 / 2 / 4 / 8)
+    if (const char* e = getenv("RTX_AHEAD_BATCH")) r->aheadBatch = std::max(1, std::min(atoi(e), r->batch));      // experiments
     if (cfg.worldSize != 1 && cfg.numDevices != -1) r->lookAhead = 0;       // a rank of a process group delivers through its own gather, once per batch (a device group looks ahead on all members)
     activate(r, 0);
     for (int b = 0; b < 4; ++b) r->queueHint[b] = r->numSlots * (uint32_t)r->batch;
@@ -1094,26 +1098,27 @@ static int build_renderer(const RtxSceneDesc* scene, const RtxConfig& cfg, const
 }
 
 // the running mean takes the frames in order: a batch's resolve waits for the resolve queued before it
-static int queue_resolve(RtxRenderer* r, const DevBatch& bt) {
+// [f0, f1): the frames of the batch that enter the running mean now
+static int queue_resolve(RtxRenderer* r, const DevBatch& bt, int f0, int f1) {
     if (r->lastResolved >= 0 && r->lastResolved != r->active)
         HIP_TRY(hipStreamWaitEvent(r->stream, r->ctx[r->lastResolved].resolved, 0));
     if (r->numSlots)
         hipLaunchKernelGGL(k_resolve, dim3((r->numSlots + RTX_BLOCK - 1) / RTX_BLOCK), dim3(RTX_BLOCK), 0, r->stream, bt, r->dTiles,
-                           r->dAcc, r->dFb);
+                           r->dAcc, r->dFb, f0, f1);
     HIP_TRY(hipEventRecord(r->ctx[r->active].resolved, r->stream));
     r->lastResolved = r->active;
     return 0;
 }
 
 // One set of launches for `count` frames (1 <= count <= r->batch), in call order.
-// ahead: a look-ahead frame (RtxRenderer::Ahead) — everything but the resolve, counted apart.
+// ahead: frames started before they are asked for (RtxRenderer::Ahead) — everything but the resolve, hits counted per frame.
 static int render_batch(RtxRenderer* r, const std::pair<RtxCamera, uint32_t>* frames, int count, bool primaryOnly, bool ahead = false) {
     HIP_TRY(hipSetDevice(r->device));
     // batches take the contexts in turn; a context's stream orders a batch after the one that used it last
     activate(r, (int)(r->frameSeq++ % r->ctx.size()));
     if (ahead) {
         r->curStats = r->ctx[r->active].dStatsAhead;
-        HIP_TRY(hipMemsetAsync(r->curStats, 0, RTX_STAT_WORDS * sizeof(unsigned long long), r->stream));
+        HIP_TRY(hipMemsetAsync(r->curStats, 0, (size_t)RTX_MAX_BATCH * RTX_STAT_WORDS * sizeof(unsigned long long), r->stream));
     }
     const int slot = r->ringPos;
     r->ringPos = (r->ringPos + 1) % kRing;
@@ -1146,11 +1151,11 @@ static int render_batch(RtxRenderer* r, const std::pair<RtxCamera, uint32_t>* fr
             }
             hipLaunchKernelGGL(k_shade, dim3(r->launchShade), dim3(RTX_BLOCK), 0, r->stream, r->sc, bt, r->dTiles, b, r->linear ? 1 : 0,
                                r->dRqO[in], r->dRqD[in], r->dHit, r->dRqO[in ^ 1], r->dRqD[in ^ 1],
-                               r->dLight, r->dAcc, r->dSeeds, r->dCtrl, r->curStats, 2 * b + 1);
+                               r->dLight, r->dAcc, r->dSeeds, r->dCtrl, r->curStats, 2 * b + 1, ahead ? 1 : 0);
             HIP_TRY(hipEventRecord(ev[2 * b + 2], r->stream));
             in ^= 1;
         }
-        if (!ahead && queue_resolve(r, bt)) return 1;
+        if (!ahead && queue_resolve(r, bt, 0, count)) return 1;
         {
             RtxRenderer::FrameCtx& c = r->ctx[r->active];
             if (!c.countsPending) {
@@ -1164,7 +1169,7 @@ static int render_batch(RtxRenderer* r, const std::pair<RtxCamera, uint32_t>* fr
         r->pending[slot] = true;
         if (ahead) {
             r->aheadSlot[slot] = true;
-            r->ahead.push_back(RtxRenderer::Ahead{frames[0].first, frames[0].second, r->active, bt, slot});
+            for (int i = 0; i < count; ++i) r->ahead.push_back(RtxRenderer::Ahead{frames[i].first, frames[i].second, r->active, bt, slot, i});
         } else {
             r->totals.frames += (uint64_t)count;
             r->primaryRays += r->localPixels * (uint64_t)count;
@@ -1178,13 +1183,14 @@ static int render_batch(RtxRenderer* r, const std::pair<RtxCamera, uint32_t>* fr
 // the look-ahead frame is the one that is asked for: its resolve, its counters
 static int take_ahead(RtxRenderer* r) {
     HIP_TRY(hipSetDevice(r->device));
-    activate(r, r->ahead.front().ctx);
-    if (queue_resolve(r, r->ahead.front().bt)) return 1;
-    hipLaunchKernelGGL(k_add_stats, dim3(1), dim3(64), 0, r->stream, r->dStats, r->ctx[r->active].dStatsAhead, RTX_STAT_WORDS);
+    const RtxRenderer::Ahead& a = r->ahead.front();
+    activate(r, a.ctx);
+    if (queue_resolve(r, a.bt, a.index, a.index + 1)) return 1;
+    hipLaunchKernelGGL(k_add_stats, dim3(1), dim3(64), 0, r->stream, r->dStats, r->ctx[r->active].dStatsAhead + (size_t)a.index * RTX_STAT_WORDS, RTX_STAT_WORDS);
     HIP_TRY(hipGetLastError());
     r->totals.frames += 1;
     r->primaryRays += r->localPixels;
-    if (r->ahead.front().ringSlot >= 0) r->aheadSlot[r->ahead.front().ringSlot] = false;      // its device time counts from here on
+    if (r->ahead.front().ringSlot >= 0) r->aheadSlot[r->ahead.front().ringSlot] = false;      // the set's device time counts from its first frame asked for
     r->ahead.pop_front();
     return 0;
 }
@@ -1199,7 +1205,32 @@ static int flush_queued(RtxRenderer* r) {
 
 // every frame queued or in flight finished (the host-side entry points that touch the framebuffer start here)
 // frames started ahead are not going to be asked for (and the loop, if there was one, is over)
-static void drop_ahead(RtxRenderer* r) { r->ahead.clear(); r->haveLast = false; r->streak = 0; r->rendersSinceDelivery = 0; }
+static void drop_ahead(RtxRenderer* r) { r->ahead.clear(); r->aheadNext = 1; r->haveLast = false; r->streak = 0; r->rendersSinceDelivery = 0; }
+
+// May another set be started ahead? Every set occupies a context until its last frame has been asked for (or all are
+// dropped); sets take the contexts in turn, so the next launch lands on the context of the oldest set. With a set
+// partly used up (the one the caller is being served from) every context may hold one; otherwise one context stays free
+// for the frame the caller asks for directly.
+static bool may_start_ahead(const RtxRenderer* r) {
+    if (r->lookAhead <= 0) return false;
+    int sets = 0, last = -1;
+    for (const RtxRenderer::Ahead& a : r->ahead) if (a.ringSlot != last) { ++sets; last = a.ringSlot; }
+    const bool partial = !r->ahead.empty() && r->ahead.front().index > 0;
+    const int limit = std::min(r->lookAhead + (partial ? 1 : 0), (int)r->ctx.size() - (partial ? 0 : 1));
+    return sets < limit;
+}
+// the next `aheadBatch` frames of the loop (same camera, consecutive frame counters) on every renderer of `all`
+static int start_ahead(RtxRenderer* const* all, int n, const RtxCamera& cam, uint32_t firstFc) {
+    RtxRenderer* r = all[0];
+    std::vector<std::pair<RtxCamera, uint32_t>> frames;
+    // the sets grow while the loop lasts (1, 2, 4 ... aheadBatch frames): a short loop, or a wrong guess early on, wastes
+    // little, a long one gets the efficiency of whole batches
+    const int count = std::max(1, std::min(r->aheadNext, r->aheadBatch));
+    for (int i = 0; i < count; ++i) frames.emplace_back(cam, firstFc + (uint32_t)i);
+    for (int k = 0; k < n; ++k) if (render_batch(all[k], frames.data(), (int)frames.size(), false, true)) return 1;
+    r->aheadNext = std::min(r->aheadBatch, count * 2);
+    return 0;
+}
 
 static int sync_all(RtxRenderer* r) {
     drop_ahead(r);
@@ -1355,10 +1386,8 @@ static int deliver(RtxRenderer* r, bool present, float gamma, void* dst) {
     }
     const bool loop = r->rendersSinceDelivery == 1 && r->streak >= 1 && r->haveLast;
     r->rendersSinceDelivery = 0;
-    while (loop && (int)r->ahead.size() < r->lookAhead) {
-        const std::pair<RtxCamera, uint32_t> next(r->lastCam, r->lastFc + 1u + (uint32_t)r->ahead.size());
-        if (render_batch(r, &next, 1, false, true)) return 1;
-    }
+    while (loop && may_start_ahead(r))
+        if (start_ahead(&r, 1, r->lastCam, r->lastFc + 1u + (uint32_t)r->ahead.size())) return 1;
     if (stage_queue(r, ds, src, bytes)) return 1;
     return stage_deliver(r, (char*)dst, bytes);
 }
@@ -1381,7 +1410,7 @@ int rtx_render(RtxRenderer* r, const RtxCamera* camera, uint32_t frameCounter, f
         const bool match = !r->ahead.empty() && r->ahead.front().fc == frameCounter && memcmp(camera, &r->ahead.front().cam, sizeof(RtxCamera)) == 0;
         for (RtxRenderer* m : all) {
             if (match && !m->ahead.empty()) { if (take_ahead(m)) return 1; continue; }
-            m->ahead.clear();
+            m->ahead.clear(); m->aheadNext = 1;
             if (!pixels_rgba && m->batch > 1) {
                 m->queued.emplace_back(*camera, frameCounter);
                 if ((int)m->queued.size() >= m->batch && flush_queued(m)) return 1;
@@ -1392,10 +1421,8 @@ int rtx_render(RtxRenderer* r, const RtxCamera* camera, uint32_t frameCounter, f
         if (gather_group(r, true, &ls)) return 1;
         const bool loop = r->rendersSinceDelivery == 1 && r->streak >= 1;
         r->rendersSinceDelivery = 0;
-        while (loop && (int)r->ahead.size() < r->lookAhead) {
-            const std::pair<RtxCamera, uint32_t> next(*camera, frameCounter + 1u + (uint32_t)r->ahead.size());
-            for (RtxRenderer* m : all) if (render_batch(m, &next, 1, false, true)) return 1;
-        }
+        while (loop && may_start_ahead(r))
+            if (start_ahead(all.data(), (int)all.size(), *camera, frameCounter + 1u + (uint32_t)r->ahead.size())) return 1;
         HIP_TRY(hipSetDevice(r->device));
         const size_t bytes = (size_t)r->width * r->height * sizeof(float4);
         if (stage_queue(r, ls, (const char*)r->dFb, bytes)) return 1;
@@ -1420,7 +1447,7 @@ static int render_one(RtxRenderer* r, const RtxCamera* camera, uint32_t frameCou
             if (take_ahead(r)) return 1;           // (nothing is collected at this point: frames are started ahead by a delivery, which renders the collection first)
             return pixels_rgba ? deliver(r, false, 0.0f, pixels_rgba) : 0;
         }
-        r->ahead.clear();                          // started for nothing
+        r->ahead.clear(); r->aheadNext = 1;        // started for nothing
     }
     if (!pixels_rgba && r->batch > 1) {
         // nothing has to be delivered yet: collect the frame; a full batch is rendered by one set of launches

@@ -543,11 +543,15 @@ __global__ __launch_bounds__(RTX_BLOCK) RTX_SHADE_ATTR void k_shade(DevScene sc,
                                                      float4* __restrict__ rqOout, float4* __restrict__ rqDout,
                                                      float4* __restrict__ lightArr, float4* __restrict__ accArr,
                                                      uint32_t* __restrict__ seeds,
-                                                     uint32_t* __restrict__ ctrl, unsigned long long* __restrict__ stats, int workIdx) {
+                                                     uint32_t* __restrict__ ctrl, unsigned long long* __restrict__ stats, int workIdx, int perFrameStats) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t nf = (uint32_t)bt.count, tilePix = (uint32_t)(bt.fr[0].tileW * bt.fr[0].tileH);
     const uint32_t count = bounce == 0 ? (uint32_t)bt.fr[0].numSlots * nf : ctrl[RTX_CTRL_COUNT(bounce)];
     uint32_t hits = 0;
+    // perFrameStats (a batch started ahead, whose frames are asked for — and counted — one by one, rtx_api.hip take_ahead):
+    // hits are counted per frame of the batch, frame f in stats[f * RTX_STAT_WORDS + ...]; wave-uniform counters
+    uint32_t hitsOf[RTX_MAX_BATCH];
+    for (int f = 0; f < RTX_MAX_BATCH; ++f) hitsOf[f] = 0;
     // Survivors go to the next queue in wave-private runs: one device atomic reserves `run` entries,
     // the wave fills them densely across iterations, and what is left of its last run when the kernel
     // ends is marked as holes (rqD.w = 1), which the trace kernels skip. One atomic per 64 paths on a
@@ -565,6 +569,7 @@ __global__ __launch_bounds__(RTX_BLOCK) RTX_SHADE_ATTR void k_shade(DevScene sc,
         bool alive = false;
         F4 o = mk4(0, 0, 0), d = mk4(0, 0, 0), light = mk4(1, 1, 1, 1), acc = mk4(0, 0, 0, 0);
         uint32_t seed = 0; int slot = 0;
+        uint32_t hitFrame = 0xffffffffu;
         if (active) {
             float4 o4 = rqOin[q], d4 = rqDin[q];
             slot = __float_as_int(o4.w);
@@ -584,6 +589,7 @@ __global__ __launch_bounds__(RTX_BLOCK) RTX_SHADE_ATTR void k_shade(DevScene sc,
                 F4 point = add4(o, mul4(dirForPoint, t));
                 F4 normal = hit_normal(prim, point);
                 const uint32_t f = nf > 1 ? ((uint32_t)slot / tilePix) % nf : 0u;      // the path's frame: its camera
+                hitFrame = f;
                 const F4 camPos = mk4(bt.fr[f].pos[0], bt.fr[f].pos[1], bt.fr[f].pos[2]);
                 F4 color = compute_color(sc, camPos, o, d, point, normal, prim, light, seed);
                 light = clamp01_sse(light);
@@ -597,6 +603,9 @@ __global__ __launch_bounds__(RTX_BLOCK) RTX_SHADE_ATTR void k_shade(DevScene sc,
             } else {
                 alive = true;
             }
+        }
+        if (perFrameStats) {
+            for (uint32_t f = 0; f < (uint32_t)RTX_MAX_BATCH; ++f) hitsOf[f] += (uint32_t)__popcll(__ballot(hitFrame == f));
         }
         // regroup survivors: dense positions in the next queue
         const unsigned long long m = __ballot(alive);
@@ -621,6 +630,12 @@ __global__ __launch_bounds__(RTX_BLOCK) RTX_SHADE_ATTR void k_shade(DevScene sc,
         }
     }
     for (uint32_t i = outCur + lane; i < outEnd; i += 64u) rqDout[i] = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
+    if (perFrameStats) {
+        if (lane == 0)
+            for (int f = 0; f < RTX_MAX_BATCH; ++f)
+                if (hitsOf[f]) atomicAdd(&stats[f * RTX_STAT_WORDS + RTX_STAT_HITS(bounce)], (unsigned long long)hitsOf[f]);
+        return;
+    }
     hits = wave_sum(hits);
     if (lane == 0 && hits) atomicAdd(&stats[RTX_STAT_HITS(bounce)], (unsigned long long)hits);
 }
@@ -629,8 +644,9 @@ __global__ __launch_bounds__(RTX_BLOCK) RTX_SHADE_ATTR void k_shade(DevScene sc,
 // frame (src/ThreadedShader.cpp:179-180). A launch of its own because frames are pipelined (several in flight
 // on separate streams) while the running mean has to take them in order: the resolve launches
 // are chained by events, everything before them overlaps freely.
+// [f0, f1): the frames of the batch to apply, in call order (a batch started ahead is applied one frame per call).
 __global__ __launch_bounds__(RTX_BLOCK) void k_resolve(DevBatch bt, const int2* __restrict__ tiles, const float4* __restrict__ accArr,
-                                                       float4* __restrict__ fb) {
+                                                       float4* __restrict__ fb, int f0, int f1) {
     const DevFrame& fr0 = bt.fr[0];
     const uint32_t p = blockIdx.x * RTX_BLOCK + threadIdx.x;
     if (p >= (uint32_t)fr0.numSlots) return;
@@ -640,7 +656,7 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_resolve(DevBatch bt, const int2* 
     const uint32_t nf = (uint32_t)bt.count, tilePix = (uint32_t)(fr0.tileW * fr0.tileH);
     const uint32_t tile = p / tilePix, within = p - tile * tilePix;
     F4 res = from4(fb[pix]);
-    for (uint32_t f = 0; f < nf; ++f)       // the frames of a batch in call order
+    for (uint32_t f = (uint32_t)f0; f < (uint32_t)f1; ++f)       // the frames of a batch in call order
         res = lerp_color(res, from4(accArr[(size_t)(tile * nf + f) * tilePix + within]), bt.fr[f].lerpScale);
     fb[pix] = make_float4(res.x, res.y, res.z, res.w);
 }
