@@ -307,7 +307,7 @@ def main():
         algo_bytes = 64.0 * inner + 48.0 * leaf
         achieved = algo_bytes / (trace_ms[b] * 1e-3) / 1e9 if trace_ms[b] > 0 else 0.0
         kname = ["k_primary", "k_trace1", "k_trace2", "k_trace3"][b]
-        traffic, tcp_accesses, traffic_source = None, None, None
+        traffic, tcp_accesses, traffic_source, pmc_counters = None, None, None, None
         digest = csrc_digest()
         pmc = os.path.join(HERE, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
@@ -317,6 +317,7 @@ def main():
                 if pj.get("csrc_sha256_16") == digest and key in pj and not args.orbit:
                     traffic = pj[key].get(kname)
                     tcp_accesses = pj.get(key + ":tcp_accesses", {}).get(kname)
+                    pmc_counters = (pj.get(key + ":counters") or {}).get(kname)
                     traffic_source = f"profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel source, csrc {digest})"
                 else:
                     traffic_source = (f"not emitted: profiles/pmc_traffic.json was taken with csrc {pj.get('csrc_sha256_16')} "
@@ -332,12 +333,34 @@ def main():
                    "culled": ["k_primary<CULLED, count>", "k_trace_refill<count, 1>", "k_trace_refill<count, 2>", "k_trace_refill<count, 3>"],
                    "exact": ["k_primary<EXACT, count>", "k_trace<EXACT, count> bounce 1", "k_trace<EXACT, count> bounce 2",
                              "k_trace<EXACT, count> bounce 3"]}[args.traversal]
-        roofline = {"bound": "hbm", "kernel": kernels[b],
+        # What limits the launch is DERIVED from the committed counters of this very kernel source (same digest gate as
+        # `traffic`), never written down by hand: HBM if the counted traffic is most of the peak, else the busiest of the CU's units.
+        launch_s = trace_ms[b] * 1e-3
+        frac_counted = (traffic / launch_s / 1e9 / HBM_PEAK_GBS) if (traffic and launch_s > 0) else None
+        L1_CEILING = 0.87          # lane loads per clock per CU the vector L1 accepts on this pattern (tools/tcp_rate, profiles/r01_tcp_rate.txt)
+        limited_by, limiter = None, None
+        if pmc_counters:
+            l1_rate = (pmc_counters["tcp_accesses"] / cu_clocks) if (pmc_counters.get("tcp_accesses") and cu_clocks > 0) else None
+            units = {"hbm": frac_counted or 0.0, "valu_issue": pmc_counters.get("valu_busy_frac") or 0.0,
+                     "vector_l1_front_end": (l1_rate / L1_CEILING) if l1_rate else 0.0}
+            limited_by = max(units, key=units.get)
+            at_ceiling = sorted(k for k, v in units.items() if v >= 0.85)
+            limiter = {"utilisation_of_each_ceiling": units, "at_or_near_ceiling": at_ceiling,
+                       "valu_busy_frac": pmc_counters.get("valu_busy_frac"), "valu_lane_util_frac": pmc_counters.get("valu_lane_util_frac"),
+                       "vector_l1_accesses_per_clock_per_cu": l1_rate, "vector_l1_ceiling_per_clock_per_cu": L1_CEILING,
+                       "l2_hit_frac": pmc_counters.get("l2_hit_frac"), "wave_time_waiting_frac": pmc_counters.get("wait_any_frac"),
+                       "l2_read_latency_cycles": pmc_counters.get("l2_read_latency_cycles"),
+                       "rocprof_avg_us_of_this_kernel": pmc_counters.get("avg_us"), "source": traffic_source}
+        roofline = {"bound": "hbm", "bound_meaning": "the roofline this gather-type fp32 kernel is priced against (no dense contraction: no MFMA); "
+                                                     "what actually limits the launch is `limited_by`, derived from the counters",
+                    "limited_by": limited_by, "limiter": limiter, "kernel": kernels[b],
                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                     "traffic": traffic, "traffic_source": traffic_source,
                     "hbm_traffic_gbs": (traffic / (trace_ms[b] * 1e-3) / 1e9) if (traffic and trace_ms[b] > 0) else None,
-                    "limiter": "not HBM: VALU issue (busy 1.06) and the vector L1's access rate (0.79 of 0.87 per clock per CU), both at their ceilings at once (DESIGN.md section 6); "
-                               "`achieved` prices device-counted visits at SURVEY 8d's 64 B / 48 B, most of which the L2 / Infinity Cache serve",
+                    "frac_meaning": "`achieved` / `frac` price device-counted visits at SURVEY 8d's 64 B / 48 B (algorithmic bytes, most of which the L2 / "
+                                    "Infinity Cache serve); frac_requested = bytes the loads ask for; frac_counted = PMC-counted HBM-side traffic: the HBM utilisation proper",
+                    "frac_requested": ((node_bytes * inner + leaf_bytes * leaf) / launch_s / 1e9 / HBM_PEAK_GBS) if launch_s > 0 else None,
+                    "frac_counted": frac_counted,
                     "algorithmic_bytes_per_launch": algo_bytes, "launch_ms": trace_ms[b],
                     "launch_ms_overlapped_in_timed_region": [kernel_ms[0], kernel_ms[2], kernel_ms[4], kernel_ms[6]][b],
                     "node_steps_per_ray": [cc.innerVisits[i] / max(1, cc.raysPerBounce[i]) for i in range(4)],
@@ -424,7 +447,13 @@ def main():
             dt = time.perf_counter() - t1
             return st.rays / dt / 1e6, f"rows {y0}..{y0 + rows} of {H} ({rows * W} pixels) of frame {fc} of the same scene, {st.rays} rays, {dt:.1f} s"
         v, sample = time_oracle(None, args.cpu_seconds)
+        try:
+            import psutil
+            physical = psutil.cpu_count(logical=False)
+        except Exception:
+            physical = None
         cpu = {"value": v, "unit": "Mrays/s", "cores": cores, "kind": "port",
+               "cores_note": f"threads used = the CPU share of a one-GPU box (at most 16); the machine has {physical} physical cores ({os.cpu_count()} logical)",
                "sample": sample + "; oracle/liboracle.so = strict -O2 restatement of ThreadedShader, static row bands as src/ThreadedShader.cpp:186-207"}
         Lf = oracle.lib_ofast()
         if Lf is not None:

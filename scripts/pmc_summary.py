@@ -119,7 +119,15 @@ def main():
                       "are counted, not excluded",
              workload: {n: (hbm(ks[0]) if ks else None) for n, ks in names.items()},
              # accesses the vector L1 (TCP) counted for the same launches: lanes of a wave that read one address are merged
-             workload + ":tcp_accesses": {n: (out.get(ks[0], {}).get("TCP_TOTAL_CACHE_ACCESSES_sum") if ks else None) for n, ks in names.items()}}
+             workload + ":tcp_accesses": {n: (out.get(ks[0], {}).get("TCP_TOTAL_CACHE_ACCESSES_sum") if ks else None) for n, ks in names.items()},
+             # what the counters say about the same launches (bench.py derives roofline.limited_by from these, never from prose)
+             workload + ":counters": {n: ({"kernel": ks[0], "avg_us": out[ks[0]].get("avg_us"), "gpu_cycles": out[ks[0]].get("GRBM_GUI_ACTIVE"),
+                                           "valu_busy_frac": out[ks[0]].get("valu_busy_frac"), "valu_lane_util_frac": out[ks[0]].get("valu_lane_util_frac"),
+                                           "l2_hit_frac": out[ks[0]].get("l2_hit_frac"), "wait_any_frac": out[ks[0]].get("wait_any_frac"),
+                                           "l2_read_latency_cycles": out[ks[0]].get("l2_read_latency_cycles"),
+                                           "tcp_accesses": out[ks[0]].get("TCP_TOTAL_CACHE_ACCESSES_sum"), "tcp_tcc_read_req": out[ks[0]].get("TCP_TCC_READ_REQ_sum"),
+                                           "waves": out[ks[0]].get("SQ_WAVES"), "valu_insts": out[ks[0]].get("SQ_INSTS_VALU")} if ks else None)
+                                      for n, ks in names.items()}}
         open(sys.argv[3], "w").write(json.dumps(t, indent=1) + "\n")
     for k in sorted(out, key=lambda k: -out[k].get("total_ms", 0)):
         o = out[k]
