@@ -252,6 +252,13 @@ def main():
     if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    # the one device-to-host copy that closes the timed region, once more on its own (nothing is queued, the frame is resident):
+    # it follows the last resolve and overlaps nothing, so elapsed - d2h is the time to the finished frame in HBM
+    d2h_s = 0.0
+    if rank == 0:
+        t1 = time.perf_counter()
+        shader.download_into(frame)
+        d2h_s = time.perf_counter() - t1
 
     rays_local = float(c.rays)
     t = torch.tensor([elapsed], dtype=torch.float64, device=red_device)
@@ -481,6 +488,9 @@ def main():
                           "timed_region": "K x rtx_render(pixels=NULL) + tile gather to rank 0 + one device-to-host copy of the frame",
                           "frames_in_flight": info.framesInFlight, "frames_per_batch": info.framesPerBatch,
                           "GPU_MAX_HW_QUEUES": info.hwQueues},
+               "value_device_resident": {"value": rays / max(elapsed - d2h_s, 1e-9) / 1e6, "unit": "Mrays/s", "final_d2h_copy_ms": d2h_s * 1e3,
+                                         "note": "the same timed region without its closing PCIe copy (K frames + tile gather, finished frame resident in HBM on rank 0); "
+                                                 "`value` keeps the copy in, as in earlier rounds"},
                "sync_boundary": sync, "culled_opt_in": culled,
                "roofline": roofline, "cpu_baseline": cpu, "extra": extra}
         print(json.dumps(out), flush=True)
