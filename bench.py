@@ -159,6 +159,12 @@ def main():
     if (int(os.environ.get("WORLD_SIZE", "1")) > 1 or (args.mode == "group" and args.gpus > 1)) and int(os.environ.get("GPU_MAX_HW_QUEUES", "4")) < 16:
         os.environ["GPU_MAX_HW_QUEUES"] = "16"
 
+    # stdout carries the JSON line and nothing else: libraries that write to file descriptor 1 on their own (RCCL prints a version
+    # banner there when the process group initialises, gloo its connection chatter) are sent to stderr for the whole run
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -493,7 +499,7 @@ def main():
                                                  "`value` keeps the copy in, as in earlier rounds"},
                "sync_boundary": sync, "culled_opt_in": culled,
                "roofline": roofline, "cpu_baseline": cpu, "extra": extra}
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=json_out, flush=True)
     if use_dist:
         dist.destroy_process_group()
 
