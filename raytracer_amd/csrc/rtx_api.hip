@@ -49,6 +49,24 @@ static_assert((RTX_QENTRY(-4, 15) >> 4) == -4 && (RTX_QENTRY(-4, 15) & 15) == 15
 static_assert((RTX_QENTRY(1 << 27, 1) >> 4) != (1 << 27), "2^27 is where the encoding wraps: kQuantMaxLeaves must stay below it");
 static_assert(RTX_QENTRY(5, 3) == rtxbuild::q_entry(5, 3) && rtxbuild::q_entry_base(rtxbuild::q_entry(-2, 9)) == -2, "host mirror of the entry encoding");
 
+// The runtime's first steps on a device — its initialisation, and loading this library's code object there, which the
+// first symbol lookup or kernel launch on a device triggers — are taken by the thread that calls rtx_create, before
+// any helper thread makes a HIP call. (Leaving them to a thread that uploads the raw arrays while the caller's thread
+// went on to its own first HIP calls ended, about once in twenty fresh processes, in a segmentation fault inside that
+// first rtx_create: tests/spill_check.py run in a loop.) Also records where the device keeps its copy of scratch[].
+static int ensure_device_ready(int device) {
+    if (device < 0 || device >= kMaxDevices) return fail("device ordinal out of range");
+    HIP_TRY(hipSetDevice(device));
+    std::lock_guard<std::mutex> g(g_scratchMutex);
+    if (!g_scratch[device]) {
+        unsigned char* ptr = nullptr;
+        HIP_TRY(hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch)));
+        HIP_TRY(hipDeviceSynchronize());
+        g_scratch[device] = ptr;
+    }
+    return 0;
+}
+
 struct RtxRenderer;
 static const int kRing = 32;      // frames whose timing events are kept; a frame's timing is read kLag frames later
 static const int kLag = 16;
@@ -830,6 +848,9 @@ int rtx_create(const RtxSceneDesc* scene, const RtxConfig* cfgIn, RtxRenderer** 
     const bool wantFast = cfg.traversal != RTX_TRAVERSE_EXACT;
     const bool wantQuant = cfg.traversal == RTX_TRAVERSE_WIDE && !getenv("RTX_WIDE_ORDERED");
     PhaseClock createClock;
+    // every device of this renderer is first touched here, by the caller's thread
+    if (cfg.numDevices > 1) { for (int i = 0; i < cfg.numDevices; ++i) if (ensure_device_ready(cfg.devices[i])) return 1; }
+    else if (ensure_device_ready(cfg.device)) return 1;
     // the raw arrays start for the (first) device now; the records are written there once the leaf order is known
     RawUpload raw;
     if (useBVH && !getenv("RTX_UPLOAD_LATE")) raw.start(cfg.numDevices > 1 ? cfg.devices[0] : cfg.device, scene);
@@ -922,15 +943,7 @@ static int build_renderer(const RtxSceneDesc* scene, const RtxConfig& cfg, const
     hipDeviceProp_t prop;
     CREATE_HIP(hipGetDeviceProperties(&prop, r->device));
     r->numCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    if (r->device < 0 || r->device >= kMaxDevices) { fail("device ordinal out of range"); rtx_destroy(r); return 1; }
-    {   // once per device, with that device current: where this device keeps its copy of scratch[]
-        std::lock_guard<std::mutex> g(g_scratchMutex);
-        if (!g_scratch[r->device]) {
-            unsigned char* ptr = nullptr;
-            CREATE_HIP(hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch)));
-            g_scratch[r->device] = ptr;
-        }
-    }
+    CREATE_TRY(ensure_device_ready(r->device));      // (rtx_create has been here already, on its own thread; a member of a group is built on a helper thread)
     size_t freeBefore = 0, freeAfter = 0, totalMem = 0;
     CREATE_HIP(hipMemGetInfo(&freeBefore, &totalMem));
     if (raw && raw->started && raw->device == r->device) {      // the raw arrays are on this device already (and go away again below)

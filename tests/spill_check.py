@@ -16,30 +16,43 @@ from raytracer_amd.renderer import HIPShader  # noqa: E402
 from raytracer_amd.scene import synthetic_scene  # noqa: E402
 
 
+def note(*a):
+    """progress on stderr, unbuffered: if the process dies, the last line says where"""
+    print("[spill_check]", *a, file=sys.stderr, flush=True)
+
+
 def main():
+    note("start")
     assert os.environ.get("RTX_HIP_LIB", "").endswith("qn2.so") or os.environ.get("RTX_SPILL_ANY_LIB") == "1"
     s = synthetic_scene(200_000, 640, 416, seed=3, tex_size=64, nthreads=8)
     d, cam = s.desc(), s.camera
+    note("scene built")
     assert cam.front.x == 0.0 and cam.front.y == 0.0 and cam.right.y == 0.0 and cam.up.x == 0.0      # axis-aligned
     want_ids = oracle.primary_hits(d, cam, 0, nthreads=8)
     want = np.zeros((d.height, d.width, 4), np.float32)
     for f in range(3):
         oracle.render(d, cam, f, want, 8)
+    note("oracle frames done")
     o, dr = oracle.primary_rays(d, cam, 0)
     dirs = dr.reshape(d.height, d.width, 4)
     assert (dirs[..., 0] == 0.0).sum() > d.height // 2, "no axis-parallel primary rays"
     bad = 0
     for rep in range(3):                                  # the overlap is a race between waves: a few rounds
         for trav in (_capi.TRAVERSE_WIDE, _capi.TRAVERSE_EXACT):
+            note("round", rep, "traversal", trav, "create")
             r = HIPShader(s, traversal=trav)
+            note("created")
             if trav == _capi.TRAVERSE_WIDE:
                 assert r.info().wideTreeDepth >= 4, r.info().wideTreeDepth
             ids = r.primary_hits(0)
+            note("primary hits done")
             px = np.zeros_like(want)
             for f in range(3):
                 r.frame_counter = f
                 r.Render(px)
+                note("frame", f, "done")
             r.close()
+            note("closed")
             nid = int((ids != want_ids).sum())
             npx = int((px.view(np.uint32) != want.view(np.uint32)).any(axis=2).sum())
             if nid or npx:
