@@ -186,6 +186,10 @@ def test_rejects_bad_input(scene1):
     cfg = _capi.Config(tileW=12, tileH=8)
     d = scene1.desc()
     assert L.rtx_create(C.byref(d), C.byref(cfg), C.byref(h)) != 0
+    cfg = _capi.Config(numDevices=-1)                # the internal marker of a device-group member is not for callers
+    assert L.rtx_create(C.byref(d), C.byref(cfg), C.byref(h)) != 0 and b"numDevices" in L.rtx_last_error()
+    cfg = _capi.Config(device=63)                    # no such GPU
+    assert L.rtx_create(C.byref(d), C.byref(cfg), C.byref(h)) != 0
 
 
 def test_empty_scene_renders_sky(libs):
