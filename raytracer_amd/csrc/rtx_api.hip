@@ -27,7 +27,7 @@ static int fail(const std::string& m) { g_err = m; return 1; }
 #define HIP_TRY(expr)                                                                        \
     do {                                                                                     \
         hipError_t e_ = (expr);                                                              \
-        if (e_ != hipSuccess) return fail(std::string(#expr) + ": " + hipGetErrorString(e_)); \
+        if (e_ != hipSuccess) { (void)hipGetLastError(); return fail(std::string(#expr) + ": " + hipGetErrorString(e_)); } \
     } while (0)
 
 // ---- scratch of rtx_trace_rays_noalloc --------------------------------------------------------------------------
@@ -937,7 +937,7 @@ static int build_renderer(const RtxSceneDesc* scene, const RtxConfig& cfg, const
     r->tileW = cfg.tileW; r->tileH = cfg.tileH;
 
 #define CREATE_TRY(expr) do { if (expr) { rtx_destroy(r); return 1; } } while (0)
-#define CREATE_HIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { fail(std::string(#expr) + ": " + hipGetErrorString(e_)); rtx_destroy(r); return 1; } } while (0)
+#define CREATE_HIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { (void)hipGetLastError(); fail(std::string(#expr) + ": " + hipGetErrorString(e_)); rtx_destroy(r); return 1; } } while (0)
 
     CREATE_HIP(hipSetDevice(r->device));
     hipDeviceProp_t prop;

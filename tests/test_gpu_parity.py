@@ -190,6 +190,12 @@ def test_rejects_bad_input(scene1):
     assert L.rtx_create(C.byref(d), C.byref(cfg), C.byref(h)) != 0 and b"numDevices" in L.rtx_last_error()
     cfg = _capi.Config(device=63)                    # no such GPU
     assert L.rtx_create(C.byref(d), C.byref(cfg), C.byref(h)) != 0
+    # a refused create leaves nothing behind (no sticky runtime error): the next renderer works
+    r = HIPShader(scene1)
+    px = np.zeros((r.height, r.width, 4), np.float32)
+    r.Render(px)
+    check_fb(px, golden("scene1_fb_f1.npy"))
+    r.close()
 
 
 def test_empty_scene_renders_sky(libs):
