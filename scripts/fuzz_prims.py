@@ -63,7 +63,7 @@ for seed in range(first, first + count):
     err = float(np.abs(np.where(fin, a - b, 0.0)).max())
     same_inf = bool((np.where(fin, 0.0, a) == np.where(fin, 0.0, b)).all())
     exact = bool((a.view(np.uint32) == b.view(np.uint32)).all())
-    flag = "" if (same_nan and same_inf and err <= 2e-3 and ok_ids) else "   <-- MISMATCH"
+    flag = "" if (same_nan and same_inf and err <= 2e-3 and ok_ids and exact) else "   <-- MISMATCH"
     bad += bool(flag)
     print(f"seed {seed:3d} objs {len(s.objects):4d} {w}x{h} bvh {use_bvh} frames {len(frames)} nan px {int(nan.any(axis=2).sum()):5d} max|d| {err:.2e} bit-identical {exact} ids {ok_ids}{flag}", flush=True)
 print(f"{count} cases, {bad} mismatches, {time.time() - t0:.0f} s")

@@ -53,7 +53,7 @@ for seed in range(first, first + count):
     a, b = np.where(nan, 0.0, got), np.where(nan, 0.0, want)
     err = float(np.abs(a - b).max())
     exact = bool((a == b).all())
-    flag = "" if (same_nan and err <= 2e-3 and ok_ids) else "   <-- MISMATCH"
+    flag = "" if (same_nan and err <= 2e-3 and ok_ids and exact) else "   <-- MISMATCH"
     bad += bool(flag)
     print(f"seed {seed:3d} tris {ntri:6d} {w}x{h} world {world} frames {len(frames):2d} max|d| {err:.2e} bit-identical {exact} ids {ok_ids}{flag}", flush=True)
 print(f"{count} cases, {bad} mismatches, {time.time() - t0:.0f} s")
