@@ -32,6 +32,16 @@ int main(int argc, char** argv) {
         Raw<Node4> wide; int d4 = 0;
         collapse4(bin.data(), bin.size(), root, wide, d4, threads);
         double t2 = now();
+        {   // expected node steps of a random line: summed surface area of the wide nodes over the root's (what the fold minimises)
+            auto node_box = [&](const Node4& nd, int& kids) { Box u = empty_box(); kids = 0;
+                for (int k = 0; k < 4; ++k) { if (f2i(nd.q[24 + k]) == (int32_t)0x80000000) continue; Box c; for (int a = 0; a < 3; ++a) { c.lo[a] = nd.q[8 * a + k]; c.hi[a] = nd.q[8 * a + 4 + k]; } grow(u, c); ++kids; }
+                return u; };
+            int kids = 0; const double rootArea = half_area(node_box(wide[0], kids));
+            double sum = 0, leafSum = 0; size_t children = 0;
+            for (const Node4& nd : wide) { sum += half_area(node_box(nd, kids)); children += (size_t)kids;
+                for (int k = 0; k < 4; ++k) { const int32_t r = f2i(nd.q[24 + k]); if (r < 0 && r != (int32_t)0x80000000) { Box c; for (int a = 0; a < 3; ++a) { c.lo[a] = nd.q[8 * a + k]; c.hi[a] = nd.q[8 * a + 4 + k]; } leafSum += half_area(c); } } }
+            printf("   SAH: expected wide-node steps of a random line %.2f, leaf boxes pierced %.2f (%.2f children per node)\n", sum / rootArea, leafSum / rootArea, (double)children / wide.size());
+        }
         Raw<NodeQ> q; std::vector<uint32_t> n2o;
         double ph[3] = {0, 0, 0};
         const bool ok = quantize4(wide, q, n2o, threads, ph);
