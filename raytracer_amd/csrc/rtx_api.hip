@@ -112,6 +112,7 @@ struct RtxRenderer {
     int launchTrace = 0, launchShade = 0;   // grids of the next launch (set_grids): smaller for short queues
     uint32_t queueHint[4] = {0, 0, 0, 0};   // expected queue length per bounce, from the last frame whose counts arrived
     size_t ldsTrace = 0;
+    bool leafQueue = false;          // bounce launches test leaves on compacted lanes (k_trace_qw)
 
     // Frames in flight: each has its own stream and its own per-path state / queues / work counters, so that
     // the thin tails of one frame's launches overlap with the next frame's work. The fields above
@@ -735,7 +736,10 @@ void dispatch_trace(RtxRenderer* r, const float4* o, const float4* d, int countI
         switch (countIdx * 4 + (r->cfg.countStats ? 2 : 0) + (big ? 1 : 0)) {
 #define RTX_REFILL_CASE(B, C, G)                                                                                              \
         case (B) * 4 + ((C) ? 2 : 0) + ((G) ? 1 : 0):                                                                          \
-            if (quant)                                                                                                         \
+            if (quant && r->leafQueue)                                                                                         \
+            hipLaunchKernelGGL((k_trace_qw<C, B, G>), dim3(r->launchTrace), dim3(RTX_BLOCK), RTX_TRACEQW_LDS_BYTES, r->stream, r->sc, \
+                               o, d, r->dHit, r->dCtrl, r->curStats, r->dSlow, fixedCount, workIdx);               \
+            else if (quant)                                                                                                    \
             hipLaunchKernelGGL((k_trace_q<C, B, G>), dim3(r->launchTrace), dim3(RTX_BLOCK), r->ldsTrace, r->stream, r->sc,     \
                                o, d, r->dHit, r->dCtrl, r->curStats, r->dSlow, fixedCount, workIdx);               \
             else                                                                                                               \
@@ -1035,8 +1039,9 @@ static int build_renderer(const RtxSceneDesc* scene, const RtxConfig& cfg, const
     // culled path: a fixed window of the stack in LDS; exact path: the whole stack (refs only)
     r->ldsTrace = r->linear ? 0 : (quant ? (size_t)RTX_QWORDS : culled ? (size_t)2 * RTX_LDS_WINDOW : (size_t)r->sc.stackDepth) * RTX_BLOCK * sizeof(int);
 
+    r->leafQueue = quant && getenv("RTX_LEAFQ") && atoi(getenv("RTX_LEAFQ")) != 0;
     int blocksPerCU = 8;
-    if (r->ldsTrace) blocksPerCU = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / r->ldsTrace));
+    if (r->ldsTrace) blocksPerCU = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / std::max<size_t>(r->ldsTrace, r->leafQueue ? (size_t)RTX_TRACEQW_LDS_BYTES : 0)));
     r->gridTrace = r->numCUs * blocksPerCU;
     if (culled) r->ldsSlow = (size_t)std::max(2, flat.maxDepth + 2) * RTX_BLOCK * sizeof(int);
     // Streams beyond the hardware queues of the process share a queue and serialise (measured: 4 frames on the

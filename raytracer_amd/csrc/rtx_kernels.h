@@ -509,6 +509,136 @@ __global__ __launch_bounds__(RTX_BLOCK) RTX_TRACEQ_ATTR void k_trace_q(DevScene 
     }
 }
 
+// k_trace_q with the leaf tests on compacted lanes (rtx_traverse.h: QWave). A lane's pass is a node step only; the leaves
+// a step finds go to the wave's queue and are tested 64 at a time by whichever lanes. A ray whose nodes have run out keeps
+// its lane (origin, direction and queue index stay in its registers) until the queue has been emptied at the next refill;
+// its result is then read from the wave's LDS. Same queue protocol and outputs as k_trace_q.
+// LDS: RTX_QN node-stack words per lane, then RTX_WQ_WORDS per wave.
+#define RTX_TRACEQW_LDS_BYTES ((RTX_QN * RTX_BLOCK + (RTX_BLOCK / 64) * RTX_WQ_WORDS) * 4)
+template <bool COUNT, int BOUNCE, bool BIG>
+__global__ __launch_bounds__(RTX_BLOCK) RTX_TRACEQ_ATTR void k_trace_qw(DevScene sc, const float4* __restrict__ rqO, const float4* __restrict__ rqD,
+                                                        int2* __restrict__ hit,
+                                                        uint32_t* __restrict__ ctrl, unsigned long long* __restrict__ stats,
+                                                        uint32_t* __restrict__ slowList, uint32_t fixedCount, int workIdx) {
+    const int countIdx = BOUNCE;
+    const uint32_t lane = threadIdx.x & 63u;
+    const unsigned long long laneLt = (1ull << lane) - 1ull;
+    const long long nthreads = (long long)gridDim.x * RTX_BLOCK;
+    const long long gtid = (long long)blockIdx.x * RTX_BLOCK + threadIdx.x;
+    QStack st;
+    st.lds = (int)threadIdx.x; st.stride = RTX_BLOCK; st.spill = (int*)sc.spill + gtid; st.spillStride = nthreads; st.nsp = 0; st.nbase = 0; st.lsp = 0;
+    QWave wq;
+    wq.init(RTX_QN * RTX_BLOCK + (int)(threadIdx.x >> 6) * RTX_WQ_WORDS);
+    unsigned long long* const myKey = (unsigned long long*)&rtx_lds[wq.key + 2 * (int)lane];
+    const uint4* __restrict__ nodes = sc.qnodes;
+    const float4* __restrict__ leaves = sc.leaf;
+    const uint32_t count = countIdx == 0 ? fixedCount : ctrl[RTX_CTRL_COUNT(countIdx)];
+    if ((unsigned long long)blockIdx.x * (RTX_BLOCK * RTX_RAYS_PER_LANE) >= (unsigned long long)count && blockIdx.x > 0) return;
+    uint32_t ic = 0, lc = 0, wp = 0;
+    uint32_t rcur = 0, rend = 0;          // wave-uniform: the wave's reserved run of the queue
+    const uint32_t segLen = segment_length(count);
+    uint32_t seg = blockIdx.x & 7u, segsTried = 0;
+    bool drained = false;                 // wave-uniform
+    // per-lane ray state
+    bool busy = false;                    // has nodes to visit
+    bool owing = false;                   // holds a ray whose result is not written yet
+    uint32_t q = 0;
+    float dx = 0, dy = 0, dz = 0;
+    QRay r = q_ray(0, 0, 0, 1, 1, 1);
+    int nodeCur = 0;
+    for (;;) {
+        // the leaves still queued, then the results of the rays that only waited for them
+        while (wq.tail != wq.head) {
+            const uint32_t left = wq.tail - wq.head;
+            q_wave_serve<COUNT>(leaves, wq, left < 64u ? left : 64u, lane, r.ox, r.oy, r.oz, r.ix, r.iy, r.iz, dx, dy, dz, lc);
+        }
+        if (owing && !busy) {
+            const unsigned long long key = __hip_atomic_load(myKey, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            hit[q] = make_int2((int)(uint32_t)(key >> 32), rtx_lds[wq.leaf + (int)lane]);
+            owing = false;
+        }
+        const unsigned long long idle = __ballot(!busy);
+        int nIdle = __popcll(idle);
+        if (!drained && nIdle >= RTX_REFILL_MIN) {
+            while (rcur >= rend && !drained) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(&ctrl[RTX_CTRL_XWORK(workIdx, seg)], RTX_RESERVE);
+                const uint32_t segStart = seg * segLen, segEnd = segStart + segLen < count ? segStart + segLen : count;
+                rcur = segStart + __builtin_amdgcn_readfirstlane(base);
+                rend = rcur + RTX_RESERVE < segEnd ? rcur + RTX_RESERVE : segEnd;
+                if (rcur >= segEnd || segStart >= count) {
+                    rend = rcur;
+                    seg = (seg + 1u) & 7u;
+                    if (++segsTried == 8u) drained = true;
+                }
+            }
+            if (!drained) {
+                // straight-line refill, as in k_trace_q
+                const uint32_t avail = rend - rcur;
+                const uint32_t take = (uint32_t)nIdle < avail ? (uint32_t)nIdle : avail;
+                const uint32_t rank = (uint32_t)__popcll(idle & laneLt);
+                const bool mine = !busy && rank < take;
+                const uint32_t qn = mine ? rcur + rank : rcur;
+                const float4 o = rqO[qn], d = rqD[qn];
+                const bool hole = d.w != 0.0f;
+                const bool clean = q_lane_ok(o.x, o.y, o.z, d.x, d.y, d.z);
+                const QRay nr = q_ray(o.x, o.y, o.z, 1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                const bool start = mine && !hole && clean;
+                q = mine ? qn : q;
+                dx = start ? d.x : dx; dy = start ? d.y : dy; dz = start ? d.z : dz;
+                r.ox = start ? nr.ox : r.ox; r.oy = start ? nr.oy : r.oy; r.oz = start ? nr.oz : r.oz;
+                r.ix = start ? nr.ix : r.ix; r.iy = start ? nr.iy : r.iy; r.iz = start ? nr.iz : r.iz;
+                r.nx = start ? nr.nx : r.nx; r.ny = start ? nr.ny : r.ny; r.nz = start ? nr.nz : r.nz;
+#if RTX_QFAST
+                r.ex = start ? nr.ex : r.ex; r.ey = start ? nr.ey : r.ey; r.ez = start ? nr.ez : r.ez;
+#endif
+                st.nsp = start ? 0 : st.nsp; st.nbase = start ? 0 : st.nbase;
+                nodeCur = start ? RTX_QENTRY(0, 1) : nodeCur;
+                if (start) {
+                    __hip_atomic_store(myKey, RTX_WQ_NOHIT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                    rtx_lds[wq.leaf + (int)lane] = -1;
+                }
+                busy = busy || start;
+                owing = owing || start;
+                if (mine && hole) hit[qn] = make_int2(0, RTX_INVALID_SLOT);
+                if (mine && !hole && !clean) slowList[atomicAdd(&ctrl[RTX_CTRL_SLOW(countIdx)], 1u)] = qn;
+                rcur += take;
+            }
+            continue;
+        }
+        if (nIdle == 64) break;          // drained and nothing in flight
+        do {
+            if (COUNT) wp++;
+            // every lane loads a node (an idle one node 0: those reads merge), so that the loads sit in straight-line code
+            const int nodeIdx = busy ? (nodeCur >> 4) + (__ffs(nodeCur & 15) - 1) : 0;
+            const QNodeData nd = q_load_node<BIG>(nodes, nodeIdx);
+            uint32_t ml = 0; int bl = 0;
+            if (busy) {
+                nodeCur &= nodeCur - 1;
+                int bi; uint32_t leafBits;
+                const uint32_t m = q_step(nd, r, bi, bl, leafBits);
+                if (COUNT) ic++;
+                const uint32_t mi = m & ~leafBits;
+                ml = m & leafBits;
+                if (mi) { if (nodeCur & 15) st.push_node(nodeCur); nodeCur = RTX_QENTRY(bi, mi); }
+                if (!(nodeCur & 15) && st.nsp > 0) nodeCur = st.pop_node();
+                busy = (nodeCur & 15) != 0;
+            }
+            q_wave_push(wq, lane, bl, ml);
+            if (wq.tail - wq.head >= 64u)
+                q_wave_serve<COUNT>(leaves, wq, 64u, lane, r.ox, r.oy, r.oz, r.ix, r.iy, r.iz, dx, dy, dz, lc);
+            nIdle = __popcll(__ballot(!busy));
+        } while (drained ? nIdle < 64 : nIdle < RTX_REFILL_MIN);
+    }
+    if (COUNT) {
+        ic = wave_sum(ic); lc = wave_sum(lc);
+        if (lane == 0) {
+            atomicAdd(&stats[RTX_STAT_INNER(countIdx)], (unsigned long long)ic); atomicAdd(&stats[RTX_STAT_LEAF(countIdx)], (unsigned long long)lc);
+            atomicAdd(&stats[RTX_STAT_PASSES(countIdx)], (unsigned long long)wp);
+        }
+    }
+}
+
 // The few rays whose slab arithmetic can produce NaN (a zero direction component: 0*inf) keep the
 // reference's topology and the reference's exact semantics. Full-depth stack in LDS (small grid).
 template <bool COUNT>

@@ -601,6 +601,105 @@ __device__ __forceinline__ Hit traverse_q(const DevScene& sc, float ox, float oy
     return best;
 }
 
+// ---- leaf tests on compacted lanes (k_trace_q with RTX_LEAFQ) ------------------------------------------------------------
+// In q_pass the leaf section runs in practically every pass of a wave (some lane holds a leaf) with about a fifth of its
+// lanes active. Here the lanes of a wave hand the leaves their node steps find to a queue of the WAVE — one entry
+// (leaf base << 4 | slot mask, owner lane) per node step that found any — and whenever 64 entries have gathered, the wave
+// expands them into single leaves and tests those 64 at a time, each lane testing a leaf of whichever ray it belongs to: the
+// ray comes from its owner's registers (ds_bpermute), the result goes into the owner's (t, ~box) key in LDS with a 64-bit
+// minimum — the reference's rule "smaller t, among equal t the larger box" (see q_leaf) as one unsigned comparison, so the
+// order in which a ray's leaves are tested does not matter, as before. A leaf is still tested iff its own exact box passes
+// the reference's arithmetic, with the same operations on the same operands: which lane evaluates them changes nothing.
+// Per-wave LDS (ints, from `key`): 64 keys (2 words each) | 64 best leaves | RTX_WQ_ENTRIES queue entries | 256 expanded
+// leaves | owner lanes of the entries and of the expanded leaves (bytes).
+#ifndef RTX_LEAFQ
+#define RTX_LEAFQ 0
+#endif
+#define RTX_WQ_ENTRIES 128u      // a pass adds at most 64 and the queue is served as soon as it holds 64
+#define RTX_WQ_WORDS (128 + 64 + (int)RTX_WQ_ENTRIES + 256 + (int)RTX_WQ_ENTRIES / 4 + 256 / 4)
+#define RTX_WQ_NOHIT 0x7f800000ffffffffull      // (+inf, no box)
+struct QWave {
+    int key, leaf, q, s, qOwner, sOwner;      // int indices into rtx_lds (qOwner, sOwner: byte indices)
+    uint32_t head, tail;                      // wave-uniform: entries [head, tail) wait in the queue
+    __device__ __forceinline__ void init(int firstWord) {
+        key = firstWord; leaf = key + 128; q = leaf + 64; s = q + (int)RTX_WQ_ENTRIES; qOwner = (s + 256) * 4; sOwner = qOwner + (int)RTX_WQ_ENTRIES;
+        head = 0; tail = 0;
+    }
+};
+__device__ __forceinline__ uint32_t q_mbcnt(unsigned long long m) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); }
+__device__ __forceinline__ float q_from_lane(float v, int byteAddr) { return __int_as_float(__builtin_amdgcn_ds_bpermute(byteAddr, __float_as_int(v))); }
+
+// a lane's node step found leaves (mask != 0): one entry each; wave-uniform control flow
+__device__ __forceinline__ void q_wave_push(QWave& w, uint32_t lane, int baseLeaf, uint32_t mask) {
+    const unsigned long long has = __ballot(mask != 0u);
+    if (has) {
+        const uint32_t slot = (w.tail + q_mbcnt(has)) & (RTX_WQ_ENTRIES - 1u);
+        if (mask) {
+            rtx_lds[w.q + (int)slot] = RTX_QENTRY(baseLeaf, mask);
+            ((unsigned char*)rtx_lds)[w.qOwner + (int)slot] = (unsigned char)lane;
+        }
+        w.tail += (uint32_t)__popcll(has);
+    }
+}
+
+// The first n (<= 64, wave-uniform) entries of the queue: expanded, tested, merged. ox .. dz: THIS lane's ray (read by the
+// lanes that test its leaves).
+template <bool COUNT>
+__device__ __forceinline__ void q_wave_serve(const float4* __restrict__ leaves, QWave& w, uint32_t n, uint32_t lane,
+                                             float ox, float oy, float oz, float ix, float iy, float iz, float dx, float dy, float dz,
+                                             uint32_t& leafCount) {
+    unsigned char* const lds8 = (unsigned char*)rtx_lds;
+    __builtin_amdgcn_wave_barrier();
+    const bool valid = lane < n;
+    const uint32_t slot = (w.head + lane) & (RTX_WQ_ENTRIES - 1u);
+    const int e = valid ? rtx_lds[w.q + (int)slot] : 0;
+    const unsigned char own = lds8[w.qOwner + (int)slot];
+    const uint32_t m = (uint32_t)e & 15u;
+    const int base = e >> 4;
+    const uint32_t c = (uint32_t)__popc(m);
+    const unsigned long long b0 = __ballot((c & 1u) != 0u), b1 = __ballot((c & 2u) != 0u), b2 = __ballot((c & 4u) != 0u);
+    uint32_t p = q_mbcnt(b0) + 2u * q_mbcnt(b1) + 4u * q_mbcnt(b2);
+    const uint32_t total = (uint32_t)__popcll(b0) + 2u * (uint32_t)__popcll(b1) + 4u * (uint32_t)__popcll(b2);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (m & (1u << k)) { rtx_lds[w.s + (int)p] = base + k; lds8[w.sOwner + (int)p] = own; ++p; }
+    w.head += n;
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t c0 = 0; c0 < total; c0 += 64u) {
+        const bool act = c0 + lane < total;
+        const uint32_t j = act ? c0 + lane : 0u;
+        const int leafIdx = rtx_lds[w.s + (int)j];
+        const int owner = (int)lds8[w.sOwner + (int)j];
+        const QLeafData d = q_load_leaf(leaves, leafIdx);
+        const int oa = owner << 2;
+        const float rox = q_from_lane(ox, oa), roy = q_from_lane(oy, oa), roz = q_from_lane(oz, oa);
+        const float rix = q_from_lane(ix, oa), riy = q_from_lane(iy, oa), riz = q_from_lane(iz, oa);
+        const float rdx = q_from_lane(dx, oa), rdy = q_from_lane(dy, oa), rdz = q_from_lane(dz, oa);
+        const bool nx = rix < 0.0f, ny = riy < 0.0f, nz = riz < 0.0f;
+        const float4 q0 = d.q0, q1 = d.q1, q2 = d.q2, q3 = d.q3;
+        const float lx = q2.z, ly = q2.w, lz = q3.x, hx = q3.y, hy = q3.z, hz = q3.w;
+        const float tn = fmaxf(((nx ? hx : lx) - rox) * rix, fmaxf(((ny ? hy : ly) - roy) * riy, ((nz ? hz : lz) - roz) * riz));
+        const float tf = fminf(((nx ? lx : hx) - rox) * rix, fminf(((ny ? ly : hy) - roy) * riy, ((nz ? lz : hz) - roz) * riz));
+        if (act && tn <= tf && tf > 0.0f) {
+            const int tag = __float_as_int(q2.y);
+            const int box = tag >> 3;
+            float t;
+            if ((tag & 7) == 4) t = intersect_triangle(rox, roy, roz, rdx, rdy, rdz, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x);
+            else t = intersect_sphere(rox, roy, roz, rdx, rdy, rdz, q0.x, q0.y, q0.z, q0.w);
+            if (COUNT) leafCount++;
+            if (t > 0.01f && t < INFINITY) {
+                // (+inf never wins in q_leaf either: not below an initial +inf, and no finite best equals it)
+                const unsigned long long key = ((unsigned long long)__float_as_uint(t) << 32) | (uint32_t)~box;
+                unsigned long long* const slotKey = (unsigned long long*)&rtx_lds[w.key + 2 * owner];
+                __hip_atomic_fetch_min(slotKey, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                // several lanes may have lowered one ray's key in that instruction: the one whose key stands names the leaf
+                if (__hip_atomic_load(slotKey, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) == key) rtx_lds[w.leaf + owner] = leafIdx;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // Linear list (src/ThreadedShader.cpp:219-237): leaves are stored in object order.
 template <bool COUNT>
 __device__ __forceinline__ Hit traverse_linear(const DevScene& sc, float ox, float oy, float oz, float dx, float dy, float dz,
