@@ -1039,7 +1039,7 @@ static int build_renderer(const RtxSceneDesc* scene, const RtxConfig& cfg, const
     // culled path: a fixed window of the stack in LDS; exact path: the whole stack (refs only)
     r->ldsTrace = r->linear ? 0 : (quant ? (size_t)RTX_QWORDS : culled ? (size_t)2 * RTX_LDS_WINDOW : (size_t)r->sc.stackDepth) * RTX_BLOCK * sizeof(int);
 
-    r->leafQueue = quant && getenv("RTX_LEAFQ") && atoi(getenv("RTX_LEAFQ")) != 0;
+    r->leafQueue = quant && !(getenv("RTX_LEAFQ") && atoi(getenv("RTX_LEAFQ")) == 0);      // RTX_LEAFQ=0: the per-lane leaf section of k_trace_q (A/B)
     int blocksPerCU = 8;
     if (r->ldsTrace) blocksPerCU = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / std::max<size_t>(r->ldsTrace, r->leafQueue ? (size_t)RTX_TRACEQW_LDS_BYTES : 0)));
     r->gridTrace = r->numCUs * blocksPerCU;

@@ -669,14 +669,17 @@ __device__ __forceinline__ void q_wave_serve(const float4* __restrict__ leaves, 
         const bool act = c0 + lane < total;
         const uint32_t j = act ? c0 + lane : 0u;
         const int leafIdx = rtx_lds[w.s + (int)j];
-        const int owner = (int)lds8[w.sOwner + (int)j];
         const QLeafData d = q_load_leaf(leaves, leafIdx);
+        const int owner = (int)lds8[w.sOwner + (int)j];
         const int oa = owner << 2;
         const float rox = q_from_lane(ox, oa), roy = q_from_lane(oy, oa), roz = q_from_lane(oz, oa);
         const float rix = q_from_lane(ix, oa), riy = q_from_lane(iy, oa), riz = q_from_lane(iz, oa);
         const float rdx = q_from_lane(dx, oa), rdy = q_from_lane(dy, oa), rdz = q_from_lane(dz, oa);
         const bool nx = rix < 0.0f, ny = riy < 0.0f, nz = riz < 0.0f;
-        const float4 q0 = d.q0, q1 = d.q1, q2 = d.q2, q3 = d.q3;
+        float4 q0 = d.q0, q1 = d.q1, q2 = d.q2, q3 = d.q3;
+        // the whole record is taken here, in one round trip: left to itself the compiler moves the loads of the primitive's part
+        // into the branch below, behind the wait for the box
+        asm volatile("" : "+v"(q0.x), "+v"(q0.y), "+v"(q0.z), "+v"(q0.w), "+v"(q1.x), "+v"(q1.y), "+v"(q1.z), "+v"(q1.w), "+v"(q2.x), "+v"(q2.y));
         const float lx = q2.z, ly = q2.w, lz = q3.x, hx = q3.y, hy = q3.z, hz = q3.w;
         const float tn = fmaxf(((nx ? hx : lx) - rox) * rix, fmaxf(((ny ? hy : ly) - roy) * riy, ((nz ? hz : lz) - roz) * riz));
         const float tf = fminf(((nx ? lx : hx) - rox) * rix, fminf(((ny ? ly : hy) - roy) * riy, ((nz ? lz : hz) - roz) * riz));
