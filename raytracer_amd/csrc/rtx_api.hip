@@ -701,11 +701,12 @@ void dispatch_trace(RtxRenderer* r, const float4* o, const float4* d, int countI
 
 template <int MODE>
 void launch_primary(RtxRenderer* r, const DevBatch& bt, int workIdx) {
+    const size_t lds = (RTX_PRIMARY_LEAFQ && (MODE == RTX_MODE_WIDEQ || MODE == RTX_MODE_WIDEQ_BIG)) ? std::max<size_t>(r->ldsTrace, RTX_TRACEQW_LDS_BYTES) : r->ldsTrace;
     if (r->cfg.countStats)
-        hipLaunchKernelGGL((k_primary<MODE, true>), dim3(r->launchTrace), dim3(RTX_BLOCK), r->ldsTrace, r->stream, r->sc, bt, r->dTiles,
+        hipLaunchKernelGGL((k_primary<MODE, true>), dim3(r->launchTrace), dim3(RTX_BLOCK), lds, r->stream, r->sc, bt, r->dTiles,
                            r->dRqO[0], r->dRqD[0], r->dHit, r->dSeeds, r->dCtrl, r->curStats, workIdx);
     else
-        hipLaunchKernelGGL((k_primary<MODE, false>), dim3(r->launchTrace), dim3(RTX_BLOCK), r->ldsTrace, r->stream, r->sc, bt, r->dTiles,
+        hipLaunchKernelGGL((k_primary<MODE, false>), dim3(r->launchTrace), dim3(RTX_BLOCK), lds, r->stream, r->sc, bt, r->dTiles,
                            r->dRqO[0], r->dRqD[0], r->dHit, r->dSeeds, r->dCtrl, r->curStats, workIdx);
 }
 template <int MODE>

@@ -186,6 +186,11 @@ __device__ __forceinline__ void primary_ray(const DevFrame& fr, int x, int y, ui
 #else
 #define RTX_PRIMARY_ATTR
 #endif
+// LDS of the kernels that test leaves on compacted lanes: RTX_QN node-stack words per lane, then RTX_WQ_WORDS per wave
+#define RTX_TRACEQW_LDS_BYTES ((RTX_QN * RTX_BLOCK + (RTX_BLOCK / 64) * RTX_WQ_WORDS) * 4)
+#ifndef RTX_PRIMARY_LEAFQ
+#define RTX_PRIMARY_LEAFQ 1        // WIDE: primary rays with the leaf tests on compacted lanes too (needs RTX_TRACEQW_LDS_BYTES of LDS)
+#endif
 template <int MODE, bool COUNT>
 __global__ __launch_bounds__(RTX_BLOCK) RTX_PRIMARY_ATTR void k_primary(DevScene sc, DevBatch bt, const int2* __restrict__ tiles,
                                                        float4* __restrict__ rqO, float4* __restrict__ rqD,
@@ -210,6 +215,33 @@ __global__ __launch_bounds__(RTX_BLOCK) RTX_PRIMARY_ATTR void k_primary(DevScene
         }
         const DevFrame& fr = bt.fr[f];
         int x, y;
+#if RTX_PRIMARY_LEAFQ
+        if (MODE == RTX_MODE_WIDEQ || MODE == RTX_MODE_WIDEQ_BIG) {
+            // the wave walks together: node steps per lane, leaf tests on compacted lanes (rtx_traverse.h: QWave)
+            const bool inside = slot_to_pixel(fr, tiles, p, x, y);
+            uint32_t seed = 0; F4 o = mk4(0, 0, 0), d = mk4(1, 1, 1);
+            if (inside) primary_ray(fr, x, y, seed, o, d);
+            const bool clean = inside && q_lane_ok(o.x, o.y, o.z, d.x, d.y, d.z);
+            QStack st;
+            st.lds = (int)threadIdx.x; st.stride = RTX_BLOCK;
+            st.spill = (int*)(sc.spill + ((long long)blockIdx.x * RTX_BLOCK + threadIdx.x)); st.spillStride = 2 * (long long)gridDim.x * RTX_BLOCK;      // see closest_hit
+            QWave wq;
+            wq.init(RTX_QN * RTX_BLOCK + (int)(threadIdx.x >> 6) * RTX_WQ_WORDS);
+            Hit h = traverse_q_wave<COUNT, MODE == RTX_MODE_WIDEQ_BIG>(sc, clean, o.x, o.y, o.z, d.x, d.y, d.z, st, wq, threadIdx.x & 63u, ic, lc);
+            if (__any(inside && !clean)) {
+                if (inside && !clean) h = traverse_bvh<true, COUNT>(sc, o.x, o.y, o.z, d.x, d.y, d.z, (int*)(sc.spill + ((long long)blockIdx.x * RTX_BLOCK + threadIdx.x)), (int)(2 * (long long)gridDim.x * RTX_BLOCK), ic, lc);
+            }
+            if (inside) {
+                rqO[slot] = make_float4(o.x, o.y, o.z, __int_as_float((int)slot));
+                rqD[slot] = make_float4(d.x, d.y, d.z, 0.0f);
+                hit[slot] = make_int2(__float_as_int(h.t), h.leaf);
+                seeds[slot] = seed;
+            } else {
+                hit[slot] = make_int2(0, RTX_INVALID_SLOT);
+            }
+            continue;
+        }
+#endif
         if (slot_to_pixel(fr, tiles, p, x, y)) {
             uint32_t seed; F4 o, d;
             primary_ray(fr, x, y, seed, o, d);
@@ -513,8 +545,7 @@ __global__ __launch_bounds__(RTX_BLOCK) RTX_TRACEQ_ATTR void k_trace_q(DevScene 
 // a step finds go to the wave's queue and are tested 64 at a time by whichever lanes. A ray whose nodes have run out keeps
 // its lane (origin, direction and queue index stay in its registers) until the queue has been emptied at the next refill;
 // its result is then read from the wave's LDS. Same queue protocol and outputs as k_trace_q.
-// LDS: RTX_QN node-stack words per lane, then RTX_WQ_WORDS per wave.
-#define RTX_TRACEQW_LDS_BYTES ((RTX_QN * RTX_BLOCK + (RTX_BLOCK / 64) * RTX_WQ_WORDS) * 4)
+// LDS: RTX_TRACEQW_LDS_BYTES.
 template <bool COUNT, int BOUNCE, bool BIG>
 __global__ __launch_bounds__(RTX_BLOCK) RTX_TRACEQ_ATTR void k_trace_qw(DevScene sc, const float4* __restrict__ rqO, const float4* __restrict__ rqD,
                                                         int2* __restrict__ hit,

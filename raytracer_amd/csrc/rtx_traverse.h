@@ -453,9 +453,12 @@ struct QStack {
     }
     __device__ __forceinline__ int pop_node() {
         nsp--;
-        if (nsp >= nbase) return rtx_lds[lds + (nsp & (RTX_QN - 1)) * stride];
-        nbase = nsp;
-        return spill[(long long)nsp * spillStride];
+        // the LDS slot is read whether or not the entry still lives there: written as "LDS or else HBM" the two loads become
+        // one flat_load through a selected pointer, and every pop waits on the flat path
+        int e = rtx_lds[lds + (nsp & (RTX_QN - 1)) * stride];
+        asm volatile("" : "+v"(e));      // (keeps the two loads apart)
+        if (nsp < nbase) { nbase = nsp; e = __builtin_nontemporal_load(spill + (long long)nsp * spillStride); }
+        return e;
     }
     __device__ __forceinline__ void push_leaf(int e) { rtx_lds[lds + (RTX_QN + lsp) * stride] = e; lsp++; }
     __device__ __forceinline__ int pop_leaf() { lsp--; return rtx_lds[lds + (RTX_QN + lsp) * stride]; }
@@ -701,6 +704,46 @@ __device__ __forceinline__ void q_wave_serve(const float4* __restrict__ leaves, 
         }
         __builtin_amdgcn_wave_barrier();
     }
+}
+
+// Closest hits of a WAVE's rays, one per lane (k_primary), with the leaf tests on compacted lanes. Every lane of the wave
+// calls this together; `active`: the lane has a ray to trace. Returns the lane's hit (box is not filled in).
+template <bool COUNT, bool BIG>
+__device__ __forceinline__ Hit traverse_q_wave(const DevScene& sc, bool active, float ox, float oy, float oz, float dx, float dy, float dz,
+                                               QStack st, QWave& wq, uint32_t lane, uint32_t& innerCount, uint32_t& leafCount) {
+    const QRay r = q_ray(ox, oy, oz, 1.0f / dx, 1.0f / dy, 1.0f / dz);
+    unsigned long long* const myKey = (unsigned long long*)&rtx_lds[wq.key + 2 * (int)lane];
+    __hip_atomic_store(myKey, RTX_WQ_NOHIT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    rtx_lds[wq.leaf + (int)lane] = -1;
+    st.nsp = 0; st.nbase = 0; st.lsp = 0;
+    int nodeCur = active ? RTX_QENTRY(0, 1) : 0;         // the root is node 0
+    bool busy = active;
+    while (__any(busy)) {
+        const int nodeIdx = busy ? (nodeCur >> 4) + (__ffs(nodeCur & 15) - 1) : 0;
+        const QNodeData nd = q_load_node<BIG>(sc.qnodes, nodeIdx);
+        uint32_t ml = 0; int bl = 0;
+        if (busy) {
+            nodeCur &= nodeCur - 1;
+            int bi; uint32_t leafBits;
+            const uint32_t m = q_step(nd, r, bi, bl, leafBits);
+            if (COUNT) innerCount++;
+            const uint32_t mi = m & ~leafBits;
+            ml = m & leafBits;
+            if (mi) { if (nodeCur & 15) st.push_node(nodeCur); nodeCur = RTX_QENTRY(bi, mi); }
+            if (!(nodeCur & 15) && st.nsp > 0) nodeCur = st.pop_node();
+            busy = (nodeCur & 15) != 0;
+        }
+        q_wave_push(wq, lane, bl, ml);
+        if (wq.tail - wq.head >= 64u)
+            q_wave_serve<COUNT>(sc.leaf, wq, 64u, lane, r.ox, r.oy, r.oz, r.ix, r.iy, r.iz, dx, dy, dz, leafCount);
+    }
+    if (wq.tail != wq.head)
+        q_wave_serve<COUNT>(sc.leaf, wq, wq.tail - wq.head, lane, r.ox, r.oy, r.oz, r.ix, r.iy, r.iz, dx, dy, dz, leafCount);
+    Hit best;
+    best.t = __uint_as_float((uint32_t)(__hip_atomic_load(myKey, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) >> 32));
+    best.leaf = rtx_lds[wq.leaf + (int)lane];
+    best.box = -1;
+    return best;
 }
 
 // Linear list (src/ThreadedShader.cpp:219-237): leaves are stored in object order.
