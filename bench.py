@@ -342,7 +342,7 @@ def main():
         clock_hz = float(getattr(props, "clock_rate", 2400000)) * 1e3
         lane_loads = node_loads * inner + leaf_loads * leaf
         cu_clocks = trace_ms[b] * 1e-3 * clock_hz * props.multi_processor_count
-        kernels = {"wide": ["k_primary<WIDEQ, count>", "k_trace_q<count, 1>", "k_trace_q<count, 2>", "k_trace_q<count, 3>"],
+        kernels = {"wide": ["k_primary<WIDEQ, count>", "k_trace_qw<count, 1>", "k_trace_qw<count, 2>", "k_trace_qw<count, 3>"],
                    "culled": ["k_primary<CULLED, count>", "k_trace_refill<count, 1>", "k_trace_refill<count, 2>", "k_trace_refill<count, 3>"],
                    "exact": ["k_primary<EXACT, count>", "k_trace<EXACT, count> bounce 1", "k_trace<EXACT, count> bounce 2",
                              "k_trace<EXACT, count> bounce 3"]}[args.traversal]
