@@ -254,6 +254,53 @@ def test_tiny_trees(libs, kind):
         r.close()
 
 
+def test_coincident_primitives_tie_break(libs, monkeypatch):
+    """Several copies of the same plane and the same sphere: every ray that hits them gets the SAME t from up to six leaves,
+    and the reference's winner is decided by its visiting order alone (descending box id in the tree, ascending object id
+    in the list; src/ThreadedShader.cpp:219-237, :370-392). In the default mode those equal candidates of one ray meet in
+    one 64-bit minimum per set of leaves tested together (rtx_traverse.h: q_wave_serve) — ids and frames must still be the
+    oracle's, with the leaves tested per wave and per lane (RTX_LEAFQ=0), with and without a tree."""
+    from raytracer_amd.scene import HostScene, procedural_texture, look_at
+    def build(bvh):
+        s = HostScene(192, 128)
+        s.add_texture(procedural_texture(32, 5))
+        s.add_texture(procedural_texture(32, 6))
+        mats = [s.add_material(f"m{i}", albedo=(0.2 + 0.1 * i, 0.9 - 0.1 * i, 0.5, 1.0), roughness=0.3 + 0.1 * i,
+                               emmissionIntensity=0.2 * i) for i in range(6)]
+        for i in range(6):
+            s.add_plane((96, 10, 300), (0, 1, 0), (300, 300, 1), mats[i])          # 6 x 2 coincident triangles
+        for i in range(3):
+            s.add_sphere((70, 60, 240), 35.0, mats[5 - i])                          # 3 coincident spheres
+        s.add_cube((130, 40, 280), (30, 30, 30), mats[2])
+        s.add_cube((130, 40, 280), (30, 30, 30), mats[4])                           # and two coincident cubes
+        if bvh:
+            s.build_bvh(2)
+        cam = s.camera
+        cam.position.x, cam.position.y, cam.position.z = 96.0, 180.0, 0.0
+        look_at(cam, (96.0, 10.0, 300.0))
+        s.camera = cam
+        return s
+    for bvh in (True, False):
+        s = build(bvh)
+        d, cam = s.desc(), s.camera
+        want_ids = oracle.primary_hits(d, cam, 0)
+        assert len(np.unique(want_ids[want_ids >= 0])) >= 3
+        want = np.zeros((d.height, d.width, 4), np.float32)
+        for f in range(3):
+            oracle.render(d, cam, f, want, 2)
+        for trav, leafq in ((_capi.TRAVERSE_WIDE, "1"), (_capi.TRAVERSE_WIDE, "0"), (_capi.TRAVERSE_CULLED, "1"), (_capi.TRAVERSE_EXACT, "1")):
+            monkeypatch.setenv("RTX_LEAFQ", leafq)
+            r = HIPShader(s, traversal=trav)
+            assert (r.primary_hits(0) == want_ids).all(), (bvh, trav, leafq)
+            px = np.zeros_like(want)
+            for f in range(3):
+                r.frame_counter = f
+                r.Render(px)
+            check_fb(px, want)
+            r.close()
+    monkeypatch.delenv("RTX_LEAFQ")
+
+
 def test_one_object_tree_intersects_without_testing_the_root_box(libs):
     """A BVH of one object: box 0 is the leaf, and the reference pops it and intersects the object without ever testing a
     box (src/ThreadedShader.cpp:349-368). A root leaf box that does not contain its sphere must therefore not hide it —
