@@ -113,6 +113,7 @@ struct RtxRenderer {
     uint32_t queueHint[4] = {0, 0, 0, 0};   // expected queue length per bounce, from the last frame whose counts arrived
     size_t ldsTrace = 0;
     bool leafQueue = false;          // bounce launches test leaves on compacted lanes (k_trace_qw)
+    int lateBlocksPerCU = 4;         // blocks per CU of the launches of bounces 2 and 3 (k_trace_qw)
 
     // Frames in flight: each has its own stream and its own per-path state / queues / work counters, so that
     // the thin tails of one frame's launches overlap with the next frame's work. The fields above
@@ -738,7 +739,7 @@ void dispatch_trace(RtxRenderer* r, const float4* o, const float4* d, int countI
 #define RTX_REFILL_CASE(B, C, G)                                                                                              \
         case (B) * 4 + ((C) ? 2 : 0) + ((G) ? 1 : 0):                                                                          \
             if (quant && r->leafQueue)                                                                                         \
-            hipLaunchKernelGGL((k_trace_qw<C, B, G>), dim3(r->launchTrace), dim3(RTX_BLOCK), RTX_TRACEQW_LDS_BYTES, r->stream, r->sc, \
+            hipLaunchKernelGGL((k_trace_qw<C, B, G>), dim3((B) >= 2 ? std::min(r->launchTrace, r->numCUs * r->lateBlocksPerCU) : r->launchTrace), dim3(RTX_BLOCK), RTX_TRACEQW_LDS_BYTES, r->stream, r->sc, \
                                o, d, r->dHit, r->dCtrl, r->curStats, r->dSlow, fixedCount, workIdx);               \
             else if (quant)                                                                                                    \
             hipLaunchKernelGGL((k_trace_q<C, B, G>), dim3(r->launchTrace), dim3(RTX_BLOCK), r->ldsTrace, r->stream, r->sc,     \
@@ -1043,7 +1044,13 @@ static int build_renderer(const RtxSceneDesc* scene, const RtxConfig& cfg, const
     r->leafQueue = quant && !(getenv("RTX_LEAFQ") && atoi(getenv("RTX_LEAFQ")) == 0);      // RTX_LEAFQ=0: the per-lane leaf section of k_trace_q (A/B)
     int blocksPerCU = 8;
     if (r->ldsTrace) blocksPerCU = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / std::max<size_t>(r->ldsTrace, r->leafQueue ? (size_t)RTX_TRACEQW_LDS_BYTES : 0)));
+    if (const char* e = getenv("RTX_TRACE_BLOCKS_PER_CU")) blocksPerCU = std::max(1, std::min(atoi(e), blocksPerCU));      // experiments: room for other streams' kernels
     r->gridTrace = r->numCUs * blocksPerCU;
+    // bounces 2 and 3 start from scattered hit points: their launches are bound by cache misses (L2 hit rate 36 % against 49 % for
+    // bounce 1), and fewer rays in flight per CU miss less — 4 blocks per CU instead of 6: 1.30 -> 1.19 and 0.70 -> 0.64 ms (3: the same,
+    // 2: 1.52 / 0.72); the bounce-1 launch and k_primary lose with fewer (2.40 -> 2.56 ms at 4)
+    r->lateBlocksPerCU = std::min(4, blocksPerCU);
+    if (const char* e = getenv("RTX_TRACE_BPC_LATE")) r->lateBlocksPerCU = std::max(1, std::min(atoi(e), blocksPerCU));
     if (culled) r->ldsSlow = (size_t)std::max(2, flat.maxDepth + 2) * RTX_BLOCK * sizeof(int);
     // Streams beyond the hardware queues of the process share a queue and serialise (measured: 4 frames on the
     // default 4 queues are slower than 3), so the default depth follows GPU_MAX_HW_QUEUES, which HIP reads when
