@@ -1016,6 +1016,7 @@ static int build_renderer(const RtxSceneDesc* scene, const RtxConfig& cfg, const
     // persistent shade grid: as many blocks as are resident at once
     int shadeBlocksPerCU = 0;
     CREATE_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&shadeBlocksPerCU, k_shade, RTX_BLOCK, 0));
+    if (const char* e = getenv("RTX_SHADE_BLOCKS_PER_CU")) shadeBlocksPerCU = std::max(1, std::min(atoi(e), shadeBlocksPerCU));      // experiments
     r->gridShade = r->numCUs * std::max(1, std::min(shadeBlocksPerCU, 8));
 
     // per-path state (indexed by slot) and queues (indexed by queue position; the bounce queues hold
