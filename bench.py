@@ -153,7 +153,7 @@ def main():
     if args.gpus > 1 and args.mode == "ranks" and "WORLD_SIZE" not in os.environ:
         return self_launch(args)
 
-    # One GPU: HIP's defaults (4 hardware queues per process; batches of 8 frames, 3 in flight need no more — measured equal
+    # One GPU: HIP's defaults (4 hardware queues per process; three batches of frames in flight need no more — measured equal
     # with 16). Ranks of a multi-GPU run keep up to 14 shorter batches in flight, one stream each: they get a hardware
     # queue per stream (HIP reads this once, when the process first touches the GPU).
     if (int(os.environ.get("WORLD_SIZE", "1")) > 1 or (args.mode == "group" and args.gpus > 1)) and int(os.environ.get("GPU_MAX_HW_QUEUES", "4")) < 16:

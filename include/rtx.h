@@ -148,7 +148,7 @@ typedef struct RtxConfig {
                               mean is still updated in frame order); 1 = strictly serial; 0 -> as many as the
                               process has hardware queues for: 3 with HIP's default GPU_MAX_HW_QUEUES=4,
                               6 with GPU_MAX_HW_QUEUES=8, 14 with 16 (an environment variable HIP reads at
-                              start-up), but no more than 3 batches when frames are rendered 8 at a time
+                              start-up), but no more than 3 batches when frames are rendered in batches of 8 or more
                               (framesPerBatch); at most 16. Each batch in flight holds its own ray queues and path
                               state: about 125 B per pixel of this rank's tiles and frame of the batch */
     int32_t numDevices;    /* > 1: a DEVICE GROUP in this one process — devices[0..numDevices) each render the tiles   */
@@ -172,7 +172,8 @@ typedef struct RtxConfig {
     int32_t framesPerBatch;/* frames queued with pixels_rgba == NULL are collected and rendered `framesPerBatch` at a time by
                               one set of launches (longer queues: the thin ends of the launches are shared by the frames of a
                               batch); any call that needs results renders what has been collected first, so results do not
-                              depend on it. 0 -> 8, at most 8; 1 -> every frame is launched by the call that queues it.
+                              depend on it. 0 -> as many as fit 35 % of the free device memory with three batches in flight, at most 32 (32 at
+                              3840x2160 on a 288-GB device); 1 -> every frame is launched by the call that queues it.
                               Each frame of a batch in flight holds about 125 B per pixel of this rank's tiles. */
 } RtxConfig;
 

@@ -1021,10 +1021,17 @@ static int build_renderer(const RtxSceneDesc* scene, const RtxConfig& cfg, const
 
     // per-path state (indexed by slot) and queues (indexed by queue position; the bounce queues hold
     // up to one unfinished run of holes per shade wave on top of the live rays)
-    // frames per batch: 8, whatever the rank's share of the tiles (measured at 4K / 10 M triangles, queued frames: 6.58 ms per frame one at a time with 14 in
-    // flight, 6.27 / 6.06 / 5.95 ms in batches of 2 / 4 / 8 — the launches' thin ends are shared by the frames of a batch)
+    // Frames per batch: the thin ends of the launches are shared by the frames of a batch, and the longer the queues the less they
+    // weigh (4K / 10 M triangles, queued frames: 6.58 ms per frame one at a time with 14 in flight, 6.27 / 6.06 / 5.95 ms in batches
+    // of 2 / 4 / 8 with round 2's kernels; 5.36 / 5.17 / 5.12 / 5.05 ms in batches of 8 / 16 / 24 / 32 with round 3's). The default is
+    // as many as fit a budget — 35 % of the device memory that is free now, for the batches in flight (three by default) — up to RTX_MAX_BATCH:
+    // 32 frames at 4K (87 GB of the 288), whatever the rank's share of the tiles.
     {
-        uint64_t want = RTX_MAX_BATCH;
+        const uint64_t bytesPerSlot = 4 * sizeof(float4) + sizeof(int2) + 2 * sizeof(float4) + sizeof(uint32_t) + (culled ? sizeof(uint32_t) : 0);
+        size_t freeNow = 0, totalNow = 0;
+        CREATE_HIP(hipMemGetInfo(&freeNow, &totalNow));
+        const uint64_t fit = (uint64_t)((double)freeNow * 0.35) / std::max<uint64_t>(1, (uint64_t)(cfg.framesInFlight > 0 ? cfg.framesInFlight : 3) * std::max<uint64_t>(r->numSlots, 64) * bytesPerSlot);
+        uint64_t want = std::max<uint64_t>(1, std::min<uint64_t>(RTX_MAX_BATCH, fit));
         if (cfg.framesPerBatch > 0) want = (uint64_t)cfg.framesPerBatch;
         if (const char* e = getenv("RTX_BATCH")) want = (uint64_t)std::max(1, atoi(e));
         while (want > 1 && (uint64_t)r->numSlots * want > 0x7fffff00ull) --want;
@@ -1061,8 +1068,8 @@ static int build_renderer(const RtxSceneDesc* scene, const RtxConfig& cfg, const
     int hwQueues = 4;
     if (const char* e = getenv("GPU_MAX_HW_QUEUES")) hwQueues = std::max(1, atoi(e));
     int depth = cfg.framesInFlight > 0 ? cfg.framesInFlight : (hwQueues <= 4 ? std::max(1, hwQueues - 1) : std::min(hwQueues - 2, 14));
-    // about 24 whole frames' worth of queues in flight at most, whatever the share of the tiles: 3 batches of 8 on a single rank
-    // (9 M slots x 8 each at 4K), up to 14 batches of 8 on a rank that owns an eighth of them
+    // three batches in flight, more only when the batches are small (a caller's framesPerBatch): about 24 whole frames' worth of
+    // queues at most, whatever the share of the tiles
     if (cfg.framesInFlight <= 0 && r->batch > 1) depth = std::min(depth, std::max(3, 24 * cfg.worldSize / r->batch));
     if (const char* e = getenv("RTX_FRAMES_IN_FLIGHT")) depth = atoi(e);
     depth = std::max(1, std::min(depth, kLag));

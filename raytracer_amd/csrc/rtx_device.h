@@ -101,7 +101,9 @@ struct DevFrame {
 // renders up to RTX_MAX_BATCH queued frames together, so its ray queues are as long as a whole frame's.
 // Batch slot s = (tile * count + frame) * tilePixels + pixel-in-tile: the frames of one tile are neighbours,
 // so a queue segment is still an image region (and the same few nodes serve all of a tile's frames).
-#define RTX_MAX_BATCH 8
+#ifndef RTX_MAX_BATCH
+#define RTX_MAX_BATCH 32
+#endif
 struct DevBatch {
     DevFrame fr[RTX_MAX_BATCH];
     int count;

@@ -766,7 +766,7 @@ __global__ __launch_bounds__(RTX_BLOCK) RTX_SHADE_ATTR void k_shade(DevScene sc,
             }
         }
         if (perFrameStats) {
-            for (uint32_t f = 0; f < (uint32_t)RTX_MAX_BATCH; ++f) hitsOf[f] += (uint32_t)__popcll(__ballot(hitFrame == f));
+            for (uint32_t f = 0; f < (uint32_t)RTX_MAX_BATCH; ++f) if (f < nf) hitsOf[f] += (uint32_t)__popcll(__ballot(hitFrame == f));
         }
         // regroup survivors: dense positions in the next queue
         const unsigned long long m = __ballot(alive);

@@ -546,10 +546,10 @@ def test_config_knobs_are_reported_and_do_not_change_results(scene1):
     whatever they are."""
     d = scene1.desc()
     out = []
-    for kw, want in ((dict(), dict(framesPerBatch=8, lookAhead=2, framesInFlight=3)),
+    for kw, want in ((dict(), dict(framesPerBatch=32, lookAhead=2, framesInFlight=3)),
                      (dict(frames_per_batch=1, look_ahead=-1, frames_in_flight=1), dict(framesPerBatch=1, lookAhead=0, framesInFlight=1)),
                      (dict(frames_per_batch=3, look_ahead=1, frames_in_flight=2), dict(framesPerBatch=3, lookAhead=1, framesInFlight=2)),
-                     (dict(frames_per_batch=100, look_ahead=9, frames_in_flight=4), dict(framesPerBatch=8, lookAhead=3, framesInFlight=4))):
+                     (dict(frames_per_batch=100, look_ahead=9, frames_in_flight=4), dict(framesPerBatch=32, lookAhead=3, framesInFlight=4))):
         r = HIPShader(scene1, **kw)
         i = r.info()
         if os.environ.get("GPU_MAX_HW_QUEUES") in (None, "4") or kw:       # the defaults depend on the hardware queues of the process
