@@ -285,7 +285,7 @@ def main():
     extra = {"scene_build_s": round(t_scene, 2), "rtx_create_s": round(t_create, 2),
              "rtx_create_phases_s": {"validate_walk": info.createSeconds[0], "own_tree": info.createSeconds[1],
                                      "records": info.createSeconds[2], "upload_alloc": info.createSeconds[3]},
-             "device_bytes": int(info.deviceBytes), "wide_nodes": int(info.wideNodes), "wide_tree_depth": info.wideTreeDepth,
+             "device_bytes": int(shader.info().deviceBytes), "device_bytes_at_create": int(info.deviceBytes), "wide_nodes": int(info.wideNodes), "wide_tree_depth": info.wideTreeDepth,
              "overlapped_kernel_ms_per_frame": dict(zip(names8, kernel_ms)),
              "device_ms_per_frame": c.totalMs / max(1, c.frames),
              "rays_per_bounce_rank0": [int(x) for x in c.raysPerBounce], "hits_per_bounce_rank0": [int(x) for x in c.hitsPerBounce]}

@@ -173,7 +173,9 @@ typedef struct RtxConfig {
                               one set of launches (longer queues: the thin ends of the launches are shared by the frames of a
                               batch); any call that needs results renders what has been collected first, so results do not
                               depend on it. 0 -> as many as fit 35 % of the free device memory with three batches in flight, at most 32 (32 at
-                              3840x2160 on a 288-GB device); 1 -> every frame is launched by the call that queues it.
+                              3840x2160 on a 288-GB device); 1 -> every frame is launched by the call that queues it. rtx_create allocates
+                              queues for 4 frames per batch in flight (what the look-ahead of the synchronous loop uses); the first
+                              frame that is queued grows them to whole batches (RtxInfo.deviceBytes follows).
                               Each frame of a batch in flight holds about 125 B per pixel of this rank's tiles. */
 } RtxConfig;
 

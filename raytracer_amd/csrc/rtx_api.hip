@@ -138,6 +138,8 @@ struct RtxRenderer {
     uint64_t frameSeq = 0;
     uint64_t primaryRays = 0;            // rays of bounce 0 since the last reset (known on the host)
     uint64_t deviceBytes = 0;            // device memory allocated by rtx_create
+    int capFrames = 0;                   // frames of a batch the contexts' queues and path state hold right now (alloc_queues / grow_queues)
+    bool needSlow = false;               // the contexts carry a side list for k_trace_slow
 
     // Frame batches: a rank that owns 1/N of the tiles has queues 1/N as long, and short launches are mostly
     // tail. Frames queued with pixels == NULL are therefore collected and up to `batch` of them rendered by one
@@ -773,6 +775,7 @@ int check_camera(const RtxCamera* cam) {
 
 } // namespace
 
+static hipError_t alloc_queues(RtxRenderer* r, int frames);
 static int build_renderer(const RtxSceneDesc* scene, const RtxConfig& cfg, const Flat& flat, bool useBVH, PhaseClock& createClock, RawUpload* raw, RtxRenderer** out);
 
 // ---------------------------------------------------------------------------------
@@ -1037,8 +1040,6 @@ static int build_renderer(const RtxSceneDesc* scene, const RtxConfig& cfg, const
         while (want > 1 && (uint64_t)r->numSlots * want > 0x7fffff00ull) --want;
         r->batch = (int)std::max<uint64_t>(1, std::min<uint64_t>(RTX_MAX_BATCH, want));
     }
-    const size_t n = std::max<size_t>((size_t)r->numSlots * r->batch, 64);
-    const size_t nq = n + (size_t)r->gridShade * (RTX_BLOCK / 64) * RTX_MAX_RUN;
     CREATE_HIP(hipMalloc((void**)&r->dStats, RTX_STAT_WORDS * sizeof(unsigned long long)));
     CREATE_HIP(hipMemset(r->dStats, 0, RTX_STAT_WORDS * sizeof(unsigned long long)));
     const size_t fbBytes = (size_t)r->width * r->height * sizeof(float4);
@@ -1079,21 +1080,13 @@ static int build_renderer(const RtxSceneDesc* scene, const RtxConfig& cfg, const
         CREATE_HIP(hipEventCreateWithFlags(&c.resolved, hipEventDisableTiming));
         CREATE_HIP(hipEventCreateWithFlags(&c.countsReady, hipEventDisableTiming));
         CREATE_HIP(hipHostMalloc((void**)&c.hCounts, 8 * sizeof(uint32_t), hipHostMallocDefault));
-        for (int k = 0; k < 2; ++k) {
-            CREATE_HIP(hipMalloc((void**)&c.dRqO[k], nq * sizeof(float4)));
-            CREATE_HIP(hipMalloc((void**)&c.dRqD[k], nq * sizeof(float4)));
-        }
-        CREATE_HIP(hipMalloc((void**)&c.dHit, nq * sizeof(int2)));
-        CREATE_HIP(hipMalloc((void**)&c.dLight, n * sizeof(float4)));
-        CREATE_HIP(hipMalloc((void**)&c.dAcc, n * sizeof(float4)));
-        CREATE_HIP(hipMalloc((void**)&c.dSeeds, n * sizeof(uint32_t)));
         CREATE_HIP(hipMalloc((void**)&c.dCtrl, RTX_CTRL_WORDS * sizeof(uint32_t)));
         CREATE_HIP(hipMalloc((void**)&c.dStatsAhead, (size_t)RTX_MAX_BATCH * RTX_STAT_WORDS * sizeof(unsigned long long)));
-        if (culled) {
-            CREATE_HIP(hipMalloc((void**)&c.dSlow, nq * sizeof(uint32_t)));
-            CREATE_HIP(hipMalloc((void**)&c.dSpill, (size_t)r->sc.stackDepth * r->gridTrace * RTX_BLOCK * sizeof(int2)));
-        }
+        if (culled) CREATE_HIP(hipMalloc((void**)&c.dSpill, (size_t)r->sc.stackDepth * r->gridTrace * RTX_BLOCK * sizeof(int2)));
     }
+    r->needSlow = culled;
+    // queues for the sets of the synchronous loop; the first queued frame grows them to whole batches (grow_queues)
+    CREATE_HIP(alloc_queues(r, getenv("RTX_QUEUES_AT_CREATE") ? r->batch : std::min(r->batch, cfg.countStats ? 1 : 4)));
     r->lookAhead = cfg.lookAhead < 0 ? 0 : std::min(cfg.lookAhead > 0 ? cfg.lookAhead : 3, depth - 1);       // 2 with HIP's default 4 hardware queues (3 contexts)
     if (const char* e = getenv("RTX_LOOKAHEAD")) r->lookAhead = std::max(0, std::min(atoi(e), depth - 1));
     r->aheadBatch = cfg.countStats ? 1 : std::min(r->batch, 4);      // (measured over 256 delivered 4K frames: 7.44 / 6.81 / 6.72 / 6.65 ms per frame with sets of 1 / 2 / 4 / 8)
@@ -1125,9 +1118,62 @@ static int build_renderer(const RtxSceneDesc* scene, const RtxConfig& cfg, const
         fprintf(stderr, "[rtx] culling slack %g (%.3f %% slivers), %d leaves, reference tree depth %d, own tree %s depth %d, stack %d entries, LDS %zu B/block, %d blocks/CU x %d CUs, mode %d\n",
                 (double)r->sc.cullSlack, 100.0 * flat.sliverFraction, r->sc.numLeaves, flat.maxDepth, flat.fast.empty() ? "absent" : "built", flat.fastDepth, r->sc.stackDepth, r->ldsTrace,
                 blocksPerCU, r->numCUs, r->mode),
-        fprintf(stderr, "[rtx] %d frames per batch, %d batches in flight (%d hardware queues), shade grid %d blocks (%d per CU), queue capacity %zu entries for %zu slots, %zu wide nodes (%.2f per leaf)\n",
-                r->batch, depth, hwQueues, r->gridShade, shadeBlocksPerCU, nq, n, flat.fast.size(), r->sc.numLeaves ? (double)flat.fast.size() / r->sc.numLeaves : 0.0);
+        fprintf(stderr, "[rtx] %d frames per batch, %d batches in flight (%d hardware queues), shade grid %d blocks (%d per CU), queues allocated for %d frames of %u slots, %zu wide nodes (%.2f per leaf)\n",
+                r->batch, depth, hwQueues, r->gridShade, shadeBlocksPerCU, r->capFrames, r->numSlots, flat.fast.size(), r->sc.numLeaves ? (double)flat.fast.size() / r->sc.numLeaves : 0.0);
     *out = r;
+    return 0;
+}
+
+// Ray queues and per-path state of every context, for batches of up to `frames` frames. rtx_create allocates them for the
+// sets the synchronous loop uses (min(batch, 4) frames); the first frame that is QUEUED (rtx_render without pixels) grows
+// them to the full batch — a caller that never queues frames (the reference's own loop) never holds the 29 GB per
+// context that a batch of 32 frames needs at 4K.
+static void free_queues(RtxRenderer* r) {
+    for (auto& c : r->ctx) {
+        void* own[] = {c.dRqO[0], c.dRqO[1], c.dRqD[0], c.dRqD[1], c.dHit, c.dLight, c.dAcc, c.dSeeds, c.dSlow};
+        for (void* p : own) if (p) hipFree(p);
+        c.dRqO[0] = c.dRqO[1] = c.dRqD[0] = c.dRqD[1] = nullptr; c.dHit = nullptr; c.dLight = c.dAcc = nullptr; c.dSeeds = c.dSlow = nullptr;
+    }
+    r->capFrames = 0;
+}
+static hipError_t alloc_queues(RtxRenderer* r, int frames) {
+    const size_t n = std::max<size_t>((size_t)r->numSlots * (size_t)frames, 64);
+    const size_t nq = n + (size_t)r->gridShade * (RTX_BLOCK / 64) * RTX_MAX_RUN;
+    hipError_t e = hipSuccess;
+    auto get = [&](void** p, size_t bytes) { if (e == hipSuccess) e = hipMalloc(p, bytes); };
+    for (auto& c : r->ctx) {
+        for (int k = 0; k < 2; ++k) { get((void**)&c.dRqO[k], nq * sizeof(float4)); get((void**)&c.dRqD[k], nq * sizeof(float4)); }
+        get((void**)&c.dHit, nq * sizeof(int2));
+        get((void**)&c.dLight, n * sizeof(float4));
+        get((void**)&c.dAcc, n * sizeof(float4));
+        get((void**)&c.dSeeds, n * sizeof(uint32_t));
+        if (r->needSlow) get((void**)&c.dSlow, nq * sizeof(uint32_t));
+    }
+    if (e != hipSuccess) { (void)hipGetLastError(); free_queues(r); return e; }
+    r->capFrames = frames;
+    return hipSuccess;
+}
+// room for full batches (r->batch frames; fewer if the device cannot hold them any more). Everything in flight finishes first.
+static int grow_queues(RtxRenderer* r) {
+    HIP_TRY(hipSetDevice(r->device));
+    HIP_TRY(hipDeviceSynchronize());
+    size_t freeBefore = 0, freeAfter = 0, total = 0;
+    HIP_TRY(hipMemGetInfo(&freeBefore, &total));
+    const int had = r->capFrames;
+    free_queues(r);
+    hipError_t e = hipSuccess;
+    for (int b = r->batch; ; b = std::max(had, b / 2)) {
+        e = alloc_queues(r, b);
+        if (e == hipSuccess) { r->batch = b; break; }
+        if (b <= std::max(1, had)) break;
+    }
+    if (e != hipSuccess) return fail(std::string("device memory for the frame queues: ") + hipGetErrorString(e));
+    HIP_TRY(hipMemGetInfo(&freeAfter, &total));
+    r->deviceBytes += (uint64_t)(freeBefore > freeAfter ? freeBefore - freeAfter : 0);
+    r->info.deviceBytes = r->deviceBytes;
+    r->info.framesPerBatch = r->batch;
+    activate(r, r->active);
+    for (int b = 0; b < 4; ++b) r->queueHint[b] = r->numSlots * (uint32_t)r->batch;
     return 0;
 }
 
@@ -1148,6 +1194,7 @@ static int queue_resolve(RtxRenderer* r, const DevBatch& bt, int f0, int f1) {
 // ahead: frames started before they are asked for (RtxRenderer::Ahead) — everything but the resolve, hits counted per frame.
 static int render_batch(RtxRenderer* r, const std::pair<RtxCamera, uint32_t>* frames, int count, bool primaryOnly, bool ahead = false) {
     HIP_TRY(hipSetDevice(r->device));
+    if (count > r->capFrames) { if (grow_queues(r)) return 1; if (count > r->capFrames) return fail("frame batch larger than the queues"); }
     // batches take the contexts in turn; a context's stream orders a batch after the one that used it last
     activate(r, (int)(r->frameSeq++ % r->ctx.size()));
     if (ahead) {
@@ -1446,6 +1493,7 @@ int rtx_render(RtxRenderer* r, const RtxCamera* camera, uint32_t frameCounter, f
             if (match && !m->ahead.empty()) { if (take_ahead(m)) return 1; continue; }
             m->ahead.clear(); m->aheadNext = 1;
             if (!pixels_rgba && m->batch > 1) {
+                if (m->capFrames < m->batch && grow_queues(m)) return 1;      // the first queued frame: room for whole batches
                 m->queued.emplace_back(*camera, frameCounter);
                 if ((int)m->queued.size() >= m->batch && flush_queued(m)) return 1;
             } else if (render_frame(m, camera, frameCounter, false)) return 1;
@@ -1485,6 +1533,7 @@ static int render_one(RtxRenderer* r, const RtxCamera* camera, uint32_t frameCou
     }
     if (!pixels_rgba && r->batch > 1) {
         // nothing has to be delivered yet: collect the frame; a full batch is rendered by one set of launches
+        if (r->capFrames < r->batch && grow_queues(r)) return 1;      // the first queued frame: room for whole batches
         r->queued.emplace_back(*camera, frameCounter);
         if ((int)r->queued.size() >= r->batch) return flush_queued(r);
         return 0;

@@ -400,6 +400,41 @@ def test_wave_pass_counter_and_queue_holes(synth_small):
     r.close()
 
 
+def test_queues_grow_with_the_first_queued_frame(synth_small, monkeypatch):
+    """rtx_create allocates ray queues and path state for the sets of the synchronous loop only (4 frames per context); the
+    first frame that is queued (Render without pixels) grows them to whole batches. A caller that only ever asks for
+    delivered frames — the reference's loop — never holds the memory of a 32-frame batch; results are those of a renderer
+    that allocates everything at create."""
+    d, cam = synth_small.desc(), synth_small.camera
+    per_frame = d.width * d.height * 100          # at least this much per frame of a batch and context (about 125 B per pixel)
+    r = HIPShader(synth_small)
+    at_create = int(r.info().deviceBytes)
+    assert r.info().framesPerBatch == 32
+    px = np.zeros((d.height, d.width, 4), np.float32)
+    for f in range(6):                            # delivered frames: the look-ahead runs its sets of up to 4 frames
+        r.frame_counter = f
+        r.Render(px)
+    assert int(r.info().deviceBytes) == at_create
+    for f in range(6, 40):                        # queued frames: one whole batch and a part of the next
+        r.frame_counter = f
+        r.Render(None)
+    got = r.download()
+    grown = int(r.info().deviceBytes)
+    assert grown - at_create > 3 * (32 - 4) * per_frame // 2, (at_create, grown)
+    c = r.counters()
+    assert c.frames == 40
+    r.close()
+    monkeypatch.setenv("RTX_QUEUES_AT_CREATE", "1")
+    r2 = HIPShader(synth_small)
+    assert abs(int(r2.info().deviceBytes) - grown) < 64 << 20
+    for f in range(40):
+        r2.frame_counter = f
+        r2.Render(None)
+    check_fb(got, r2.download())
+    assert list(r2.counters().raysPerBounce) == list(c.raysPerBounce)
+    r2.close()
+
+
 def test_frames_in_flight_keep_frame_order(scene2):
     """rtx_render(pixels = NULL) only queues the frame; several frames overlap on the device, each on its own
     stream with its own path state, while the running mean still takes them in order (k_resolve launches are
