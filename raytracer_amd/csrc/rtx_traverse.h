@@ -604,7 +604,7 @@ __device__ __forceinline__ Hit traverse_q(const DevScene& sc, float ox, float oy
     return best;
 }
 
-// ---- leaf tests on compacted lanes (k_trace_q with RTX_LEAFQ) ------------------------------------------------------------
+// ---- leaf tests on compacted lanes (k_trace_qw, k_primary) ----------------------------------------------------------------
 // In q_pass the leaf section runs in practically every pass of a wave (some lane holds a leaf) with about a fifth of its
 // lanes active. Here the lanes of a wave hand the leaves their node steps find to a queue of the WAVE — one entry
 // (leaf base << 4 | slot mask, owner lane) per node step that found any — and whenever 64 entries have gathered, the wave
@@ -615,9 +615,6 @@ __device__ __forceinline__ Hit traverse_q(const DevScene& sc, float ox, float oy
 // the reference's arithmetic, with the same operations on the same operands: which lane evaluates them changes nothing.
 // Per-wave LDS (ints, from `key`): 64 keys (2 words each) | 64 best leaves | RTX_WQ_ENTRIES queue entries | 256 expanded
 // leaves | owner lanes of the entries and of the expanded leaves (bytes).
-#ifndef RTX_LEAFQ
-#define RTX_LEAFQ 0
-#endif
 #define RTX_WQ_ENTRIES 128u      // a pass adds at most 64 and the queue is served as soon as it holds 64
 #define RTX_WQ_WORDS (128 + 64 + (int)RTX_WQ_ENTRIES + 256 + (int)RTX_WQ_ENTRIES / 4 + 256 / 4)
 #define RTX_WQ_NOHIT 0x7f800000ffffffffull      // (+inf, no box)
