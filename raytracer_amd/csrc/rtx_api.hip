@@ -1081,7 +1081,7 @@ static int build_renderer(const RtxSceneDesc* scene, const RtxConfig& cfg, const
         CREATE_HIP(hipEventCreateWithFlags(&c.countsReady, hipEventDisableTiming));
         CREATE_HIP(hipHostMalloc((void**)&c.hCounts, 8 * sizeof(uint32_t), hipHostMallocDefault));
         CREATE_HIP(hipMalloc((void**)&c.dCtrl, RTX_CTRL_WORDS * sizeof(uint32_t)));
-        CREATE_HIP(hipMalloc((void**)&c.dStatsAhead, (size_t)RTX_MAX_BATCH * RTX_STAT_WORDS * sizeof(unsigned long long)));
+        CREATE_HIP(hipMalloc((void**)&c.dStatsAhead, (size_t)RTX_AHEAD_MAX * RTX_STAT_WORDS * sizeof(unsigned long long)));
         if (culled) CREATE_HIP(hipMalloc((void**)&c.dSpill, (size_t)r->sc.stackDepth * r->gridTrace * RTX_BLOCK * sizeof(int2)));
     }
     r->needSlow = culled;
@@ -1090,7 +1090,7 @@ static int build_renderer(const RtxSceneDesc* scene, const RtxConfig& cfg, const
     r->lookAhead = cfg.lookAhead < 0 ? 0 : std::min(cfg.lookAhead > 0 ? cfg.lookAhead : 3, depth - 1);       // 2 with HIP's default 4 hardware queues (3 contexts)
     if (const char* e = getenv("RTX_LOOKAHEAD")) r->lookAhead = std::max(0, std::min(atoi(e), depth - 1));
     r->aheadBatch = cfg.countStats ? 1 : std::min(r->batch, 4);      // (measured over 256 delivered 4K frames: 7.44 / 6.81 / 6.72 / 6.65 ms per frame with sets of 1 / 2 / 4 / 8)
-    if (const char* e = getenv("RTX_AHEAD_BATCH")) r->aheadBatch = std::max(1, std::min(atoi(e), r->batch));      // experiments
+    if (const char* e = getenv("RTX_AHEAD_BATCH")) r->aheadBatch = std::max(1, std::min(atoi(e), std::min(r->batch, RTX_AHEAD_MAX)));      // experiments
     if (cfg.worldSize != 1 && cfg.numDevices != -1) r->lookAhead = 0;       // a rank of a process group delivers through its own gather, once per batch (a device group looks ahead on all members)
     activate(r, 0);
     for (int b = 0; b < 4; ++b) r->queueHint[b] = r->numSlots * (uint32_t)r->batch;
@@ -1194,12 +1194,13 @@ static int queue_resolve(RtxRenderer* r, const DevBatch& bt, int f0, int f1) {
 // ahead: frames started before they are asked for (RtxRenderer::Ahead) — everything but the resolve, hits counted per frame.
 static int render_batch(RtxRenderer* r, const std::pair<RtxCamera, uint32_t>* frames, int count, bool primaryOnly, bool ahead = false) {
     HIP_TRY(hipSetDevice(r->device));
+    if (ahead && count > RTX_AHEAD_MAX) return fail("look-ahead set larger than RTX_AHEAD_MAX");
     if (count > r->capFrames) { if (grow_queues(r)) return 1; if (count > r->capFrames) return fail("frame batch larger than the queues"); }
     // batches take the contexts in turn; a context's stream orders a batch after the one that used it last
     activate(r, (int)(r->frameSeq++ % r->ctx.size()));
     if (ahead) {
         r->curStats = r->ctx[r->active].dStatsAhead;
-        HIP_TRY(hipMemsetAsync(r->curStats, 0, (size_t)RTX_MAX_BATCH * RTX_STAT_WORDS * sizeof(unsigned long long), r->stream));
+        HIP_TRY(hipMemsetAsync(r->curStats, 0, (size_t)RTX_AHEAD_MAX * RTX_STAT_WORDS * sizeof(unsigned long long), r->stream));
     }
     const int slot = r->ringPos;
     r->ringPos = (r->ringPos + 1) % kRing;

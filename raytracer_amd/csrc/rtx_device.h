@@ -104,6 +104,7 @@ struct DevFrame {
 #ifndef RTX_MAX_BATCH
 #define RTX_MAX_BATCH 32
 #endif
+#define RTX_AHEAD_MAX 8       // most frames of a set started ahead (rtx_api.hip look-ahead): k_shade counts their hits per frame
 struct DevBatch {
     DevFrame fr[RTX_MAX_BATCH];
     int count;

@@ -709,10 +709,10 @@ __global__ __launch_bounds__(RTX_BLOCK) RTX_SHADE_ATTR void k_shade(DevScene sc,
     const uint32_t nf = (uint32_t)bt.count, tilePix = (uint32_t)(bt.fr[0].tileW * bt.fr[0].tileH);
     const uint32_t count = bounce == 0 ? (uint32_t)bt.fr[0].numSlots * nf : ctrl[RTX_CTRL_COUNT(bounce)];
     uint32_t hits = 0;
-    // perFrameStats (a batch started ahead, whose frames are asked for — and counted — one by one, rtx_api.hip take_ahead):
+    // perFrameStats (a set of at most RTX_AHEAD_MAX frames started ahead, which are asked for — and counted — one by one, rtx_api.hip take_ahead):
     // hits are counted per frame of the batch, frame f in stats[f * RTX_STAT_WORDS + ...]; wave-uniform counters
-    uint32_t hitsOf[RTX_MAX_BATCH];
-    for (int f = 0; f < RTX_MAX_BATCH; ++f) hitsOf[f] = 0;
+    uint32_t hitsOf[RTX_AHEAD_MAX];
+    for (int f = 0; f < RTX_AHEAD_MAX; ++f) hitsOf[f] = 0;
     // Survivors go to the next queue in wave-private runs: one device atomic reserves `run` entries,
     // the wave fills them densely across iterations, and what is left of its last run when the kernel
     // ends is marked as holes (rqD.w = 1), which the trace kernels skip. One atomic per 64 paths on a
@@ -766,7 +766,7 @@ __global__ __launch_bounds__(RTX_BLOCK) RTX_SHADE_ATTR void k_shade(DevScene sc,
             }
         }
         if (perFrameStats) {
-            for (uint32_t f = 0; f < (uint32_t)RTX_MAX_BATCH; ++f) if (f < nf) hitsOf[f] += (uint32_t)__popcll(__ballot(hitFrame == f));
+            for (uint32_t f = 0; f < (uint32_t)RTX_AHEAD_MAX; ++f) hitsOf[f] += (uint32_t)__popcll(__ballot(hitFrame == f));
         }
         // regroup survivors: dense positions in the next queue
         const unsigned long long m = __ballot(alive);
@@ -793,7 +793,7 @@ __global__ __launch_bounds__(RTX_BLOCK) RTX_SHADE_ATTR void k_shade(DevScene sc,
     for (uint32_t i = outCur + lane; i < outEnd; i += 64u) rqDout[i] = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
     if (perFrameStats) {
         if (lane == 0)
-            for (int f = 0; f < RTX_MAX_BATCH; ++f)
+            for (int f = 0; f < RTX_AHEAD_MAX; ++f)
                 if (hitsOf[f]) atomicAdd(&stats[f * RTX_STAT_WORDS + RTX_STAT_HITS(bounce)], (unsigned long long)hitsOf[f]);
         return;
     }
