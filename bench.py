@@ -146,6 +146,7 @@ def main():
                     help="RtxConfig.framesInFlight for the timed region: 0 = library default for the process' hardware queues, "
                          "1 = strictly serial frames")
     ap.add_argument("--orbit", action="store_true", help="-O camera: new camera + frameCounter=0 every frame (src/Main.cpp:68-82)")
+    ap.add_argument("--timed-only", action="store_true", help="profiling runs: skip the roofline pass too (the JSON line then has no roofline: not a bench line)")
     ap.add_argument("--sync-only", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.sync_only:
@@ -296,7 +297,9 @@ def main():
     # time (framesInFlight = 1, framesPerBatch = 1) with the counting instantiation of the kernels: node steps, leaf tests and the
     # HIP-event duration then come from the very same launches (the counters cost ~3 %).
     roofline = None
-    if rank == 0:
+    if rank == 0 and args.timed_only:
+        shader.close()
+    elif rank == 0:
         shader.close()
         counter = HIPShader(scene, device=local_rank, rank=rank, world_size=world, traversal=trav, count_stats=True,
                             frames_in_flight=1, frames_per_batch=1 if world == 1 else 0)

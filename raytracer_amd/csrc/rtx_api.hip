@@ -1018,7 +1018,7 @@ static int build_renderer(const RtxSceneDesc* scene, const RtxConfig& cfg, const
 
     // persistent shade grid: as many blocks as are resident at once
     int shadeBlocksPerCU = 0;
-    CREATE_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&shadeBlocksPerCU, k_shade, RTX_BLOCK, 0));
+    CREATE_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&shadeBlocksPerCU, k_shade, RTX_BLOCK, RTX_SHADE_LDS_BYTES));
     if (const char* e = getenv("RTX_SHADE_BLOCKS_PER_CU")) shadeBlocksPerCU = std::max(1, std::min(atoi(e), shadeBlocksPerCU));      // experiments
     r->gridShade = r->numCUs * std::max(1, std::min(shadeBlocksPerCU, 8));
 
@@ -1231,7 +1231,7 @@ static int render_batch(RtxRenderer* r, const std::pair<RtxCamera, uint32_t>* fr
                 dispatch_trace(r, r->dRqO[in], r->dRqD[in], b, 2 * b, 0);
                 HIP_TRY(hipEventRecord(ev[2 * b + 1], r->stream));
             }
-            hipLaunchKernelGGL(k_shade, dim3(r->launchShade), dim3(RTX_BLOCK), 0, r->stream, r->sc, bt, r->dTiles, b, r->linear ? 1 : 0,
+            hipLaunchKernelGGL(k_shade, dim3(r->launchShade), dim3(RTX_BLOCK), RTX_SHADE_LDS_BYTES, r->stream, r->sc, bt, r->dTiles, b, r->linear ? 1 : 0,
                                r->dRqO[in], r->dRqD[in], r->dHit, r->dRqO[in ^ 1], r->dRqD[in ^ 1],
                                r->dLight, r->dAcc, r->dSeeds, r->dCtrl, r->curStats, 2 * b + 1, ahead ? 1 : 0);
             HIP_TRY(hipEventRecord(ev[2 * b + 2], r->stream));

@@ -697,6 +697,10 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_trace_slow(DevScene sc, const flo
 #else
 #define RTX_SHADE_ATTR
 #endif
+#ifndef RTX_SHADE_WINDOW
+#define RTX_SHADE_WINDOW 512u     // queue entries a wave sorts into hits and misses at a time (LDS: 8 bytes each)
+#endif
+#define RTX_SHADE_LDS_BYTES ((RTX_BLOCK / 64) * 2 * RTX_SHADE_WINDOW * 4)
 // src/ThreadedShader.cpp:155-180 for bounce `bounce` of every queued path.
 __global__ __launch_bounds__(RTX_BLOCK) RTX_SHADE_ATTR void k_shade(DevScene sc, DevBatch bt, const int2* __restrict__ tiles, int bounce, int linearMode,
                                                      const float4* __restrict__ rqOin, const float4* __restrict__ rqDin,
@@ -720,28 +724,45 @@ __global__ __launch_bounds__(RTX_BLOCK) RTX_SHADE_ATTR void k_shade(DevScene sc,
     const uint32_t run = append_run_length(count);
     uint32_t outCur = 0, outEnd = 0;      // wave-uniform
     WorkIter<2, false> work(count);
+    // Hits and misses are shaded apart. A wave first sorts a window of RTX_SHADE_WINDOW queue entries into two lists (LDS:
+    // queue positions, in queue order), then shades the hits 64 at a time and the misses 64 at a time. Shading a run of 64
+    // as it comes costs the hit branch AND the sky branch whenever the run holds both — every run of bounces 1 to 3, where
+    // a third of the paths hit something — with each branch's lanes a third or two thirds full.
+    int* const hitList = rtx_lds + (threadIdx.x >> 6) * (2 * RTX_SHADE_WINDOW);
+    int* const missList = hitList + RTX_SHADE_WINDOW;
     for (;;) {
-        const uint32_t base = work.next(ctrl, workIdx);
-        if (base == 0xffffffffu) break;
-        const uint32_t q = base + lane;
-        bool active = q < count;
-        int leaf = -1; float hitDistance = 0.0f;
-        if (active) { const int2 h = hit[q]; leaf = h.y; hitDistance = __int_as_float(h.x); active = leaf != RTX_INVALID_SLOT; }
-        bool alive = false;
-        F4 o = mk4(0, 0, 0), d = mk4(0, 0, 0), light = mk4(1, 1, 1, 1), acc = mk4(0, 0, 0, 0);
-        uint32_t seed = 0; int slot = 0;
-        uint32_t hitFrame = 0xffffffffu;
-        if (active) {
-            float4 o4 = rqOin[q], d4 = rqDin[q];
-            slot = __float_as_int(o4.w);
-            o = mk4(o4.x, o4.y, o4.z); d = mk4(d4.x, d4.y, d4.z);
-            if (bounce > 0) { light = from4(lightArr[slot]); acc = from4(accArr[slot]); }
-            bool finished;
-            if (leaf < 0) {
-                F4 texel = sky_texel(sc, d);
-                acc = add4(acc, mul4(texel, light));          // no clamp on the sky term (src/ThreadedShader.cpp:169)
-                finished = true;
-            } else {
+        uint32_t nHit = 0, nMiss = 0;     // wave-uniform
+        bool any = false;
+        for (uint32_t it = 0; it < RTX_SHADE_WINDOW / 64u; ++it) {
+            const uint32_t base = work.next(ctrl, workIdx);
+            if (base == 0xffffffffu) break;
+            any = true;
+            const uint32_t q = base + lane;
+            int leaf = RTX_INVALID_SLOT;
+            if (q < count) leaf = hit[q].y;
+            const bool isHit = leaf >= 0, isMiss = leaf < 0 && leaf != RTX_INVALID_SLOT;
+            const unsigned long long bh = __ballot(isHit), bm = __ballot(isMiss);
+            if (isHit) hitList[nHit + q_mbcnt(bh)] = (int)q;
+            if (isMiss) missList[nMiss + q_mbcnt(bm)] = (int)q;
+            nHit += (uint32_t)__popcll(bh); nMiss += (uint32_t)__popcll(bm);
+        }
+        if (!any) break;
+        __builtin_amdgcn_wave_barrier();
+        // ---- the hits: ComputeColor, survivors to the next queue ----
+        for (uint32_t i0 = 0; i0 < nHit; i0 += 64u) {
+            const bool active = i0 + lane < nHit;
+            bool alive = false;
+            F4 o = mk4(0, 0, 0), d = mk4(0, 0, 0), light = mk4(1, 1, 1, 1), acc = mk4(0, 0, 0, 0);
+            uint32_t seed = 0; int slot = 0;
+            uint32_t hitFrame = 0xffffffffu;
+            if (active) {
+                const uint32_t q = (uint32_t)hitList[i0 + lane];
+                const int2 h = hit[q];
+                const int leaf = h.y; const float hitDistance = __int_as_float(h.x);
+                float4 o4 = rqOin[q], d4 = rqDin[q];
+                slot = __float_as_int(o4.w);
+                o = mk4(o4.x, o4.y, o4.z); d = mk4(d4.x, d4.y, d4.z);
+                if (bounce > 0) { light = from4(lightArr[slot]); acc = from4(accArr[slot]); }
                 hits++;
                 seed = seeds[slot];
                 HitPrim prim = load_prim(sc, leaf);
@@ -755,40 +776,54 @@ __global__ __launch_bounds__(RTX_BLOCK) RTX_SHADE_ATTR void k_shade(DevScene sc,
                 F4 color = compute_color(sc, camPos, o, d, point, normal, prim, light, seed);
                 light = clamp01_sse(light);
                 acc = clamp01_sse(add4(acc, color));
-                finished = bounce == 3;
+                if (bounce == 3) {
+                    // the path's colour waits in its slot for k_resolve: frames overlap on the device, and the
+                    // running mean must be updated in frame order
+                    accArr[slot] = make_float4(acc.x, acc.y, acc.z, acc.w);
+                } else {
+                    alive = true;
+                }
             }
-            if (finished) {
-                // the path's colour waits in its slot for k_resolve: frames overlap on the device, and the
-                // running mean must be updated in frame order
+            if (perFrameStats) {
+                for (uint32_t f = 0; f < (uint32_t)RTX_AHEAD_MAX; ++f) hitsOf[f] += (uint32_t)__popcll(__ballot(hitFrame == f));
+            }
+            // regroup survivors: dense positions in the next queue
+            const unsigned long long m = __ballot(alive);
+            if (m) {
+                const uint32_t n = (uint32_t)__popcll(m), room = outEnd - outCur;
+                uint32_t fresh = 0;
+                if (n > room) {
+                    if (lane == 0) fresh = atomicAdd(&ctrl[RTX_CTRL_COUNT(bounce + 1)], run);
+                    fresh = __builtin_amdgcn_readfirstlane(fresh);
+                }
+                if (alive) {
+                    const uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                    const uint32_t pos = rank < room ? outCur + rank : fresh + (rank - room);
+                    rqOout[pos] = make_float4(o.x, o.y, o.z, __int_as_float(slot));
+                    rqDout[pos] = make_float4(d.x, d.y, d.z, 0.0f);
+                    lightArr[slot] = make_float4(light.x, light.y, light.z, light.w);
+                    accArr[slot] = make_float4(acc.x, acc.y, acc.z, acc.w);
+                    seeds[slot] = seed;
+                }
+                if (n > room) { outCur = fresh + (n - room); outEnd = fresh + run; }
+                else outCur += n;
+            }
+        }
+        // ---- the misses: the sky's colour ends the path (src/ThreadedShader.cpp:160-171) ----
+        for (uint32_t i0 = 0; i0 < nMiss; i0 += 64u) {
+            if (i0 + lane < nMiss) {
+                const uint32_t q = (uint32_t)missList[i0 + lane];
+                const float4 o4 = rqOin[q], d4 = rqDin[q];
+                const int slot = __float_as_int(o4.w);
+                const F4 d = mk4(d4.x, d4.y, d4.z);
+                F4 light = mk4(1, 1, 1, 1), acc = mk4(0, 0, 0, 0);
+                if (bounce > 0) { light = from4(lightArr[slot]); acc = from4(accArr[slot]); }
+                const F4 texel = sky_texel(sc, d);
+                acc = add4(acc, mul4(texel, light));          // no clamp on the sky term (src/ThreadedShader.cpp:169)
                 accArr[slot] = make_float4(acc.x, acc.y, acc.z, acc.w);
-            } else {
-                alive = true;
             }
         }
-        if (perFrameStats) {
-            for (uint32_t f = 0; f < (uint32_t)RTX_AHEAD_MAX; ++f) hitsOf[f] += (uint32_t)__popcll(__ballot(hitFrame == f));
-        }
-        // regroup survivors: dense positions in the next queue
-        const unsigned long long m = __ballot(alive);
-        if (m) {
-            const uint32_t n = (uint32_t)__popcll(m), room = outEnd - outCur;
-            uint32_t fresh = 0;
-            if (n > room) {
-                if (lane == 0) fresh = atomicAdd(&ctrl[RTX_CTRL_COUNT(bounce + 1)], run);
-                fresh = __builtin_amdgcn_readfirstlane(fresh);
-            }
-            if (alive) {
-                const uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-                const uint32_t pos = rank < room ? outCur + rank : fresh + (rank - room);
-                rqOout[pos] = make_float4(o.x, o.y, o.z, __int_as_float(slot));
-                rqDout[pos] = make_float4(d.x, d.y, d.z, 0.0f);
-                lightArr[slot] = make_float4(light.x, light.y, light.z, light.w);
-                accArr[slot] = make_float4(acc.x, acc.y, acc.z, acc.w);
-                seeds[slot] = seed;
-            }
-            if (n > room) { outCur = fresh + (n - room); outEnd = fresh + run; }
-            else outCur += n;
-        }
+        __builtin_amdgcn_wave_barrier();
     }
     for (uint32_t i = outCur + lane; i < outEnd; i += 64u) rqDout[i] = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
     if (perFrameStats) {
