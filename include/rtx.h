@@ -166,7 +166,7 @@ typedef struct RtxConfig {
                               then 4 consecutive frames (it grows while the loop lasts, so that a short loop or an early
                               wrong guess wastes little), applied to the running mean one frame per call. The next call
                               either asks for the first frame started ahead or they are all dropped unused. Images and work
-                              counters are the same either way; a wrong guess costs device time only (at most ~3 sets).
+                              counters are the same either way; a wrong guess costs device time only (at most ~3 sets of up to 8 frames).
                               0 -> up to 3, at most framesInFlight - 1 (2 with HIP's default 4 hardware queues); -1 -> never.
                               A device group looks ahead on all its members. */
     int32_t framesPerBatch;/* frames queued with pixels_rgba == NULL are collected and rendered `framesPerBatch` at a time by
@@ -174,8 +174,8 @@ typedef struct RtxConfig {
                               batch); any call that needs results renders what has been collected first, so results do not
                               depend on it. 0 -> as many as fit 35 % of the free device memory with three batches in flight, at most 32 (32 at
                               3840x2160 on a 288-GB device); 1 -> every frame is launched by the call that queues it. rtx_create allocates
-                              queues for 4 frames per batch in flight (what the look-ahead of the synchronous loop uses); the first
-                              frame that is queued grows them to whole batches (RtxInfo.deviceBytes follows).
+                              queues for 4 frames per batch in flight (the look-ahead of the synchronous loop grows them to its sets
+                              of 8); the first frame that is queued grows them to whole batches (RtxInfo.deviceBytes follows).
                               Each frame of a batch in flight holds about 125 B per pixel of this rank's tiles. */
 } RtxConfig;
 

@@ -131,6 +131,8 @@ struct RtxRenderer {
         bool countsPending = false;
         int countsFrames = 1;              // how many frames those counts belong to
         unsigned long long* dStatsAhead = nullptr;   // work counters of a look-ahead frame, added to dStats when the frame is asked for
+        int capFrames = 0;                 // frames of a batch this context's queues and path state hold (alloc_ctx)
+        uint64_t queueBytes = 0;           // what alloc_ctx asked the device for
     };
     std::vector<FrameCtx> ctx;
     int active = 0;
@@ -138,7 +140,7 @@ struct RtxRenderer {
     uint64_t frameSeq = 0;
     uint64_t primaryRays = 0;            // rays of bounce 0 since the last reset (known on the host)
     uint64_t deviceBytes = 0;            // device memory allocated by rtx_create
-    int capFrames = 0;                   // frames of a batch the contexts' queues and path state hold right now (alloc_queues / grow_queues)
+    int capFrames = 0;                   // frames of a batch EVERY context's queues and path state hold right now (alloc_queues / grow_queues / grow_ctx)
     bool needSlow = false;               // the contexts carry a side list for k_trace_slow
 
     // Frame batches: a rank that owns 1/N of the tiles has queues 1/N as long, and short launches are mostly
@@ -1089,7 +1091,9 @@ static int build_renderer(const RtxSceneDesc* scene, const RtxConfig& cfg, const
     CREATE_HIP(alloc_queues(r, getenv("RTX_QUEUES_AT_CREATE") ? r->batch : std::min(r->batch, cfg.countStats ? 1 : 4)));
     r->lookAhead = cfg.lookAhead < 0 ? 0 : std::min(cfg.lookAhead > 0 ? cfg.lookAhead : 3, depth - 1);       // 2 with HIP's default 4 hardware queues (3 contexts)
     if (const char* e = getenv("RTX_LOOKAHEAD")) r->lookAhead = std::max(0, std::min(atoi(e), depth - 1));
-    r->aheadBatch = cfg.countStats ? 1 : std::min(r->batch, 4);      // (measured over 256 delivered 4K frames: 7.44 / 6.81 / 6.72 / 6.65 ms per frame with sets of 1 / 2 / 4 / 8)
+    // sets of up to 8 frames (128 delivered 4K frames: 5.84 ms per frame with sets of up to 4, 5.44 - 5.49 ms with 8; round 2's kernels: 7.44 / 6.81 /
+    // 6.72 / 6.65 ms with 1 / 2 / 4 / 8, which is why the cap used to be 4)
+    r->aheadBatch = cfg.countStats ? 1 : std::min(r->batch, RTX_AHEAD_MAX);
     if (const char* e = getenv("RTX_AHEAD_BATCH")) r->aheadBatch = std::max(1, std::min(atoi(e), std::min(r->batch, RTX_AHEAD_MAX)));      // experiments
     if (cfg.worldSize != 1 && cfg.numDevices != -1) r->lookAhead = 0;       // a rank of a process group delivers through its own gather, once per batch (a device group looks ahead on all members)
     activate(r, 0);
@@ -1124,41 +1128,58 @@ static int build_renderer(const RtxSceneDesc* scene, const RtxConfig& cfg, const
     return 0;
 }
 
-// Ray queues and per-path state of every context, for batches of up to `frames` frames. rtx_create allocates them for the
-// sets the synchronous loop uses (min(batch, 4) frames); the first frame that is QUEUED (rtx_render without pixels) grows
-// them to the full batch — a caller that never queues frames (the reference's own loop) never holds the 29 GB per
-// context that a batch of 32 frames needs at 4K.
-static void free_queues(RtxRenderer* r) {
-    for (auto& c : r->ctx) {
-        void* own[] = {c.dRqO[0], c.dRqO[1], c.dRqD[0], c.dRqD[1], c.dHit, c.dLight, c.dAcc, c.dSeeds, c.dSlow};
-        for (void* p : own) if (p) hipFree(p);
-        c.dRqO[0] = c.dRqO[1] = c.dRqD[0] = c.dRqD[1] = nullptr; c.dHit = nullptr; c.dLight = c.dAcc = nullptr; c.dSeeds = c.dSlow = nullptr;
-    }
-    r->capFrames = 0;
+// Ray queues and per-path state of the contexts, for batches of up to `frames` frames. rtx_create allocates them for the
+// first sets the synchronous loop starts ahead (min(batch, 4) frames); a context grows on its own when a larger set lands
+// on it (grow_ctx: sets of 8), and the first frame that is QUEUED (rtx_render without pixels) grows all of them to the full
+// batch — a caller that never queues frames (the reference's own loop) never holds the 29 GB per context that a batch
+// of 32 frames needs at 4K.
+static void free_ctx(RtxRenderer::FrameCtx& c) {
+    void* own[] = {c.dRqO[0], c.dRqO[1], c.dRqD[0], c.dRqD[1], c.dHit, c.dLight, c.dAcc, c.dSeeds, c.dSlow};
+    for (void* p : own) if (p) hipFree(p);
+    c.dRqO[0] = c.dRqO[1] = c.dRqD[0] = c.dRqD[1] = nullptr; c.dHit = nullptr; c.dLight = c.dAcc = nullptr; c.dSeeds = c.dSlow = nullptr;
+    c.capFrames = 0; c.queueBytes = 0;
 }
-static hipError_t alloc_queues(RtxRenderer* r, int frames) {
+static hipError_t alloc_ctx(RtxRenderer* r, RtxRenderer::FrameCtx& c, int frames) {
     const size_t n = std::max<size_t>((size_t)r->numSlots * (size_t)frames, 64);
     const size_t nq = n + (size_t)r->gridShade * (RTX_BLOCK / 64) * RTX_MAX_RUN;
     hipError_t e = hipSuccess;
-    auto get = [&](void** p, size_t bytes) { if (e == hipSuccess) e = hipMalloc(p, bytes); };
+    uint64_t asked = 0;
+    auto get = [&](void** p, size_t bytes) { if (e == hipSuccess) { e = hipMalloc(p, bytes); asked += bytes; } };
+    for (int k = 0; k < 2; ++k) { get((void**)&c.dRqO[k], nq * sizeof(float4)); get((void**)&c.dRqD[k], nq * sizeof(float4)); }
+    get((void**)&c.dHit, nq * sizeof(int2));
+    get((void**)&c.dLight, n * sizeof(float4));
+    get((void**)&c.dAcc, n * sizeof(float4));
+    get((void**)&c.dSeeds, n * sizeof(uint32_t));
+    if (r->needSlow) get((void**)&c.dSlow, nq * sizeof(uint32_t));
+    if (e != hipSuccess) { (void)hipGetLastError(); free_ctx(c); return e; }
+    c.capFrames = frames; c.queueBytes = asked;
+    return hipSuccess;
+}
+static void free_queues(RtxRenderer* r) {
+    for (auto& c : r->ctx) free_ctx(c);
+    r->capFrames = 0;
+}
+static hipError_t alloc_queues(RtxRenderer* r, int frames) {
     for (auto& c : r->ctx) {
-        for (int k = 0; k < 2; ++k) { get((void**)&c.dRqO[k], nq * sizeof(float4)); get((void**)&c.dRqD[k], nq * sizeof(float4)); }
-        get((void**)&c.dHit, nq * sizeof(int2));
-        get((void**)&c.dLight, n * sizeof(float4));
-        get((void**)&c.dAcc, n * sizeof(float4));
-        get((void**)&c.dSeeds, n * sizeof(uint32_t));
-        if (r->needSlow) get((void**)&c.dSlow, nq * sizeof(uint32_t));
+        const hipError_t e = alloc_ctx(r, c, frames);
+        if (e != hipSuccess) { free_queues(r); return e; }
     }
-    if (e != hipSuccess) { (void)hipGetLastError(); free_queues(r); return e; }
     r->capFrames = frames;
     return hipSuccess;
 }
-// room for full batches (r->batch frames; fewer if the device cannot hold them any more). Everything in flight finishes first.
+// RtxInfo.deviceBytes follows the queues (by what was asked for: differences of the free memory the runtime reports say little
+// once its allocator has blocks of its own to hand out again)
+static uint64_t queue_bytes(const RtxRenderer* r) { uint64_t b = 0; for (const auto& c : r->ctx) b += c.queueBytes; return b; }
+static void account_growth(RtxRenderer* r, uint64_t queueBytesBefore) {
+    r->deviceBytes = r->deviceBytes - std::min(r->deviceBytes, queueBytesBefore) + queue_bytes(r);
+    r->info.deviceBytes = r->deviceBytes;
+}
+// room for full batches in every context (r->batch frames; fewer if the device cannot hold them any more). Everything in
+// flight finishes first.
 static int grow_queues(RtxRenderer* r) {
     HIP_TRY(hipSetDevice(r->device));
     HIP_TRY(hipDeviceSynchronize());
-    size_t freeBefore = 0, freeAfter = 0, total = 0;
-    HIP_TRY(hipMemGetInfo(&freeBefore, &total));
+    const uint64_t bytesBefore = queue_bytes(r);
     const int had = r->capFrames;
     free_queues(r);
     hipError_t e = hipSuccess;
@@ -1168,12 +1189,25 @@ static int grow_queues(RtxRenderer* r) {
         if (b <= std::max(1, had)) break;
     }
     if (e != hipSuccess) return fail(std::string("device memory for the frame queues: ") + hipGetErrorString(e));
-    HIP_TRY(hipMemGetInfo(&freeAfter, &total));
-    r->deviceBytes += (uint64_t)(freeBefore > freeAfter ? freeBefore - freeAfter : 0);
-    r->info.deviceBytes = r->deviceBytes;
+    account_growth(r, bytesBefore);
     r->info.framesPerBatch = r->batch;
     activate(r, r->active);
     for (int b = 0; b < 4; ++b) r->queueHint[b] = r->numSlots * (uint32_t)r->batch;
+    return 0;
+}
+// room for `frames` frames in context i alone, which holds nothing that is still needed (a set started ahead lands on the
+// context whose previous set has been asked for to the last frame); the other contexts go on
+static int grow_ctx(RtxRenderer* r, int i, int frames) {
+    RtxRenderer::FrameCtx& c = r->ctx[(size_t)i];
+    for (const RtxRenderer::Ahead& a : r->ahead) if (a.ctx == i) return fail("internal: a context with frames started ahead cannot grow");
+    HIP_TRY(hipStreamSynchronize(c.stream));
+    const uint64_t bytesBefore = queue_bytes(r);
+    const int had = c.capFrames;
+    free_ctx(c);
+    hipError_t e = alloc_ctx(r, c, frames);
+    if (e != hipSuccess) e = alloc_ctx(r, c, had);          // what it had, at least
+    if (e != hipSuccess) return fail(std::string("device memory for the frame queues: ") + hipGetErrorString(e));
+    account_growth(r, bytesBefore);
     return 0;
 }
 
@@ -1195,8 +1229,15 @@ static int queue_resolve(RtxRenderer* r, const DevBatch& bt, int f0, int f1) {
 static int render_batch(RtxRenderer* r, const std::pair<RtxCamera, uint32_t>* frames, int count, bool primaryOnly, bool ahead = false) {
     HIP_TRY(hipSetDevice(r->device));
     if (ahead && count > RTX_AHEAD_MAX) return fail("look-ahead set larger than RTX_AHEAD_MAX");
-    if (count > r->capFrames) { if (grow_queues(r)) return 1; if (count > r->capFrames) return fail("frame batch larger than the queues"); }
     // batches take the contexts in turn; a context's stream orders a batch after the one that used it last
+    {
+        const int next = (int)(r->frameSeq % r->ctx.size());
+        if (count > r->ctx[(size_t)next].capFrames) {
+            if (ahead) { if (grow_ctx(r, next, std::max(count, r->aheadBatch))) return 1; }
+            else if (grow_queues(r)) return 1;
+            if (count > r->ctx[(size_t)next].capFrames) return fail("frame batch larger than the queues");
+        }
+    }
     activate(r, (int)(r->frameSeq++ % r->ctx.size()));
     if (ahead) {
         r->curStats = r->ctx[r->active].dStatsAhead;
