@@ -109,3 +109,4 @@ struct DevBatch {
     DevFrame fr[RTX_MAX_BATCH];
     int count;
 };
+static_assert(RTX_AHEAD_MAX <= RTX_MAX_BATCH, "a set started ahead is a batch");
