@@ -1198,6 +1198,7 @@ static int grow_queues(RtxRenderer* r) {
 // room for `frames` frames in context i alone, which holds nothing that is still needed (a set started ahead lands on the
 // context whose previous set has been asked for to the last frame); the other contexts go on
 static int grow_ctx(RtxRenderer* r, int i, int frames) {
+    HIP_TRY(hipSetDevice(r->device));
     RtxRenderer::FrameCtx& c = r->ctx[(size_t)i];
     for (const RtxRenderer::Ahead& a : r->ahead) if (a.ctx == i) return fail("internal: a context with frames started ahead cannot grow");
     HIP_TRY(hipStreamSynchronize(c.stream));

@@ -188,6 +188,7 @@ __device__ __forceinline__ void primary_ray(const DevFrame& fr, int x, int y, ui
 #endif
 // LDS of the kernels that test leaves on compacted lanes: RTX_QN node-stack words per lane, then RTX_WQ_WORDS per wave
 #define RTX_TRACEQW_LDS_BYTES ((RTX_QN * RTX_BLOCK + (RTX_BLOCK / 64) * RTX_WQ_WORDS) * 4)
+static_assert(RTX_TRACEQW_LDS_BYTES <= 65536, "a block's LDS is at most 64 KB");
 #ifndef RTX_PRIMARY_LEAFQ
 #define RTX_PRIMARY_LEAFQ 1        // WIDE: primary rays with the leaf tests on compacted lanes too (needs RTX_TRACEQW_LDS_BYTES of LDS)
 #endif
@@ -701,6 +702,7 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_trace_slow(DevScene sc, const flo
 #define RTX_SHADE_WINDOW 512u     // queue entries a wave sorts into hits and misses at a time (LDS: 8 bytes each)
 #endif
 #define RTX_SHADE_LDS_BYTES ((RTX_BLOCK / 64) * 2 * RTX_SHADE_WINDOW * 4)
+static_assert(RTX_SHADE_LDS_BYTES <= 65536 && RTX_SHADE_WINDOW % 64u == 0u, "a block's LDS is at most 64 KB; a window is whole runs of 64");
 // src/ThreadedShader.cpp:155-180 for bounce `bounce` of every queued path.
 __global__ __launch_bounds__(RTX_BLOCK) RTX_SHADE_ATTR void k_shade(DevScene sc, DevBatch bt, const int2* __restrict__ tiles, int bounce, int linearMode,
                                                      const float4* __restrict__ rqOin, const float4* __restrict__ rqDin,
