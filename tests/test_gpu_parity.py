@@ -254,12 +254,14 @@ def test_tiny_trees(libs, kind):
         r.close()
 
 
-def test_coincident_primitives_tie_break(libs, monkeypatch):
+@pytest.mark.parametrize("copies", [6, 80])
+def test_coincident_primitives_tie_break(libs, monkeypatch, copies):
     """Several copies of the same plane and the same sphere: every ray that hits them gets the SAME t from up to six leaves,
     and the reference's winner is decided by its visiting order alone (descending box id in the tree, ascending object id
     in the list; src/ThreadedShader.cpp:219-237, :370-392). In the default mode those equal candidates of one ray meet in
     one 64-bit minimum per set of leaves tested together (rtx_traverse.h: q_wave_serve) — ids and frames must still be the
-    oracle's, with the leaves tested per wave and per lane (RTX_LEAFQ=0), with and without a tree."""
+    oracle's, with the leaves tested per wave and per lane (RTX_LEAFQ=0), with and without a tree. With 80 copies a single ray
+    queues well over a hundred leaves: more than one set of 64 for one owner lane, several expansions per ray."""
     from raytracer_amd.scene import HostScene, procedural_texture, look_at
     def build(bvh):
         s = HostScene(192, 128)
@@ -267,8 +269,8 @@ def test_coincident_primitives_tie_break(libs, monkeypatch):
         s.add_texture(procedural_texture(32, 6))
         mats = [s.add_material(f"m{i}", albedo=(0.2 + 0.1 * i, 0.9 - 0.1 * i, 0.5, 1.0), roughness=0.3 + 0.1 * i,
                                emmissionIntensity=0.2 * i) for i in range(6)]
-        for i in range(6):
-            s.add_plane((96, 10, 300), (0, 1, 0), (300, 300, 1), mats[i])          # 6 x 2 coincident triangles
+        for i in range(copies):
+            s.add_plane((96, 10, 300), (0, 1, 0), (300, 300, 1), mats[i % 6])     # copies x 2 coincident triangles
         for i in range(3):
             s.add_sphere((70, 60, 240), 35.0, mats[5 - i])                          # 3 coincident spheres
         s.add_cube((130, 40, 280), (30, 30, 30), mats[2])
