@@ -5,7 +5,59 @@
 #include <cstdio>
 #include <cstdlib>
 #include <random>
+#include <string>
+#include <algorithm>
 using namespace rtxbuild;
+// ---- evaluation only: the topology a device-side LBVH build (Morton sort + Karras) would produce, on the host ----
+static inline uint64_t spread21(uint64_t v) { v &= 0x1fffffull; v = (v | v << 32) & 0x1f00000000ffffull; v = (v | v << 16) & 0x1f0000ff0000ffull;
+    v = (v | v << 8) & 0x100f00f00f00f00full; v = (v | v << 4) & 0x10c30c30c30c30c3ull; v = (v | v << 2) & 0x1249249249249249ull; return v; }
+struct Lbvh {
+    const Box* prim; std::vector<std::pair<uint64_t, uint32_t>> keys; Node* nodes;
+    int32_t rec(uint32_t begin, uint32_t end, int32_t nodeIdx, int bit, int depth, Box& out, int& outDepth) {
+        if (end - begin == 1) { out = prim[keys[begin].second]; outDepth = depth; return ~(int32_t)begin; }
+        uint32_t mid = begin;
+        while (bit >= 0) {
+            const uint64_t m = 1ull << bit;
+            if ((keys[begin].first & m) == (keys[end - 1].first & m)) { --bit; continue; }
+            uint32_t lo = begin, hi = end - 1;      // first index with the bit set
+            while (hi - lo > 1) { const uint32_t c = lo + (hi - lo) / 2; if (keys[c].first & m) hi = c; else lo = c; }
+            mid = hi; --bit; break;
+        }
+        if (mid == begin) mid = begin + (end - begin) / 2;      // identical codes
+        const uint32_t nl = mid - begin;
+        Box bl, br; int dl = 0, dr = 0;
+        const int32_t rl = rec(begin, mid, nodeIdx + 1, bit, depth + 1, bl, dl), rr = rec(mid, end, nodeIdx + (int32_t)nl, bit, depth + 1, br, dr);
+        float* q = nodes[nodeIdx].q;
+        for (int a = 0; a < 3; ++a) { q[a] = bl.lo[a]; q[3 + a] = bl.hi[a]; q[6 + a] = br.lo[a]; q[9 + a] = br.hi[a]; }
+        q[12] = i2f(rl); q[13] = i2f(rr); q[14] = 0; q[15] = 0;
+        out = bl; grow(out, br); outDepth = std::max(dl, dr);
+        return nodeIdx;
+    }
+};
+static int32_t build_lbvh(const Box* prim, uint32_t n, uint32_t* order, Node* nodes, int& maxDepth) {
+    Box cb = empty_box();
+    for (uint32_t i = 0; i < n; ++i) { Box c; for (int a = 0; a < 3; ++a) c.lo[a] = c.hi[a] = 0.5f * prim[i].lo[a] + 0.5f * prim[i].hi[a]; grow(cb, c); }
+    Lbvh L; L.prim = prim; L.nodes = nodes; L.keys.resize(n);
+    for (uint32_t i = 0; i < n; ++i) {
+        uint64_t code = 0;
+        for (int a = 0; a < 3; ++a) {
+            const double ext = (double)cb.hi[a] - cb.lo[a], c = 0.5 * prim[i].lo[a] + 0.5 * prim[i].hi[a];
+            double u = ext > 0 ? (c - cb.lo[a]) / ext : 0.0; u = u < 0 ? 0 : (u > 1 ? 1 : u);
+            uint64_t k = (uint64_t)(u * 2097151.0);
+            code |= spread21(k) << (2 - a);
+        }
+        if (getenv("LBVH_HOIST")) {       // primitives wider than 1/8 of the scene on some axis sort behind all others: the root split sets them apart
+            bool large = false; for (int a = 0; a < 3; ++a) large = large || (prim[i].hi[a] - prim[i].lo[a]) > 0.125f * (cb.hi[a] - cb.lo[a]);
+            code = (code >> 1) | (large ? 1ull << 62 : 0);
+        }
+        L.keys[i] = {code, i};
+    }
+    std::sort(L.keys.begin(), L.keys.end());
+    Box root; int d = 0;
+    const int32_t r = L.rec(0, n, 0, 62, 0, root, d);
+    for (uint32_t i = 0; i < n; ++i) order[i] = L.keys[i].second;
+    maxDepth = d; return r;
+}
 static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 int main(int argc, char** argv) {
     const uint32_t n = argc > 1 ? (uint32_t)atoll(argv[1]) : 10000000u; const int threads = argc > 2 ? atoi(argv[2]) : 16;
@@ -27,7 +79,8 @@ int main(int argc, char** argv) {
         std::vector<uint32_t> order(n); for (uint32_t i = 0; i < n; ++i) order[i] = i;
         double t0 = now();
         Raw<Node> bin(n - 1); int d = 0;
-        const int32_t root = build_sah(prim.data(), n, order.data(), bin.data(), threads, d);
+        const bool lbvh = argc > 4 && std::string(argv[4]) == "lbvh";
+        const int32_t root = lbvh ? build_lbvh(prim.data(), n, order.data(), bin.data(), d) : build_sah(prim.data(), n, order.data(), bin.data(), threads, d);
         double t1 = now();
         Raw<Node4> wide; int d4 = 0;
         collapse4(bin.data(), bin.size(), root, wide, d4, threads);
