@@ -94,8 +94,32 @@ def sync_only(args):
         res[key] = {"ms_per_step": dt / n * 1e3, "mrays_per_s": float(c.rays) * n / (warm + n) / dt / 1e6, "frames": n, "look_ahead": info.lookAhead,
                     "hw_queues_seen": info.hwQueues}
         shader.close()
+
+    def wrong_guess_ms():
+        """The loop is left while sets of frames are ahead (the caller jumps to another frame counter): time of that one call."""
+        sh = HIPShader(scene, device=0, traversal=trav, look_ahead=0)
+        buf = np.zeros((sh.height, sh.width, 4), dtype=np.float32)
+        out, base = [], 0
+        for rep in range(3):
+            for i in range(14):                       # the loop is recognised and the sets ahead have grown to their full size
+                sh.frame_counter = base + i
+                sh.Render(buf)
+            t1 = time.perf_counter()
+            sh.frame_counter = base + 1000
+            sh.Render(buf)
+            out.append((time.perf_counter() - t1) * 1e3)
+            base += 2000
+        sh.close()
+        return min(out)
+    jump = {"sets_cut_short": wrong_guess_ms()}
+    os.environ["RTX_NO_ABORT"] = "1"
+    jump["sets_run_out"] = wrong_guess_ms()
+    del os.environ["RTX_NO_ABORT"]
+    jump["note"] = ("ms of the one synchronous Render(pixels) call that leaves the loop (another frame counter) while sets of frames are ahead: "
+                    "the library overwrites the work counters of those sets so that their launches run out at once (rtx_api.hip abort_ahead); "
+                    "sets_run_out = the same call with RTX_NO_ABORT=1")
     out = dict(res["default"])
-    out.update({"without_look_ahead": {"ms_per_step": res["no_look_ahead"]["ms_per_step"], "mrays_per_s": res["no_look_ahead"]["mrays_per_s"]},
+    out.update({"wrong_guess_ms": jump, "without_look_ahead": {"ms_per_step": res["no_look_ahead"]["ms_per_step"], "mrays_per_s": res["no_look_ahead"]["mrays_per_s"]},
                 "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"),
                 "pattern": "rtx_render(pixels) per frame, synchronous, 16 B/pixel copied to a pageable host array every frame; "
                            "look_ahead = frames the library starts before they are asked for (RtxConfig.lookAhead, same results)"})

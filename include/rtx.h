@@ -217,6 +217,9 @@ typedef struct RtxInfo {
     double   createSeconds[4]; /* validate + walk boxes, own-tree build, record emission, upload + allocation */
     int32_t  devices;          /* members of the device group this handle stands for (1: a single renderer) */
     int32_t  lookAhead;        /* frames rtx_render(pixels) starts ahead (RtxConfig.lookAhead as resolved) */
+    uint64_t setsCutShort;     /* sets of frames started ahead and never asked for whose launches were made to run out at
+                                  once (their work counters overwritten from a control stream); a running count, read at the
+                                  time of rtx_get_info, summed over the members of a device group. Results never depend on it. */
 } RtxInfo;
 
 typedef struct RtxRenderer RtxRenderer;

@@ -53,7 +53,7 @@ class Info(C.Structure):
                 ("refTreeDepth", C.c_int32), ("wideTreeDepth", C.c_int32), ("stackEntries", C.c_int32),
                 ("leaves", C.c_uint64), ("innerNodes", C.c_uint64), ("wideNodes", C.c_uint64),
                 ("sliverFraction", C.c_double), ("deviceBytes", C.c_uint64), ("createSeconds", C.c_double * 4),
-                ("devices", C.c_int32), ("lookAhead", C.c_int32)]
+                ("devices", C.c_int32), ("lookAhead", C.c_int32), ("setsCutShort", C.c_uint64)]
 
 
 # numpy mirrors of the reference PODs (sizes/offsets as in include/rtx.h)

@@ -133,6 +133,8 @@ struct RtxRenderer {
         unsigned long long* dStatsAhead = nullptr;   // work counters of a look-ahead frame, added to dStats when the frame is asked for
         int capFrames = 0;                 // frames of a batch this context's queues and path state hold (alloc_ctx)
         uint64_t queueBytes = 0;           // what alloc_ctx asked the device for
+        hipEvent_t abortDone = nullptr;    // recorded on the control stream behind an abort of this context's set (abort_ahead)
+        bool abortPending = false;         // the context's next set of launches has to wait for abortDone before it clears ctrl[]
     };
     std::vector<FrameCtx> ctx;
     int active = 0;
@@ -187,6 +189,8 @@ struct RtxRenderer {
     int lookAhead = 0;                  // how many sets of launches are started ahead (0: never)
     int aheadBatch = 1;                 // most frames per set started ahead (1 with countStats: visit counters are per set)
     int aheadNext = 1;                  // frames of the next set: 1 when a loop is recognised, doubling with every set started while it lasts
+    hipStream_t ctl = nullptr;          // control stream (highest priority, a hardware queue of its own): aborts of sets started for nothing
+    uint64_t abortedSets = 0;
 };
 
 // ---------------------------------------------------------------------------------
@@ -795,8 +799,10 @@ void rtx_destroy(RtxRenderer* r) {
     if (r->dPackedOwn) hipFree(r->dPackedOwn);
     if (r->dPresent) hipFree(r->dPresent);
     if (r->dPackedAtLeader && r->leaderDevice >= 0) { hipSetDevice(r->leaderDevice); hipFree(r->dPackedAtLeader); hipSetDevice(r->device); }
+    if (r->ctl) { hipStreamSynchronize(r->ctl); hipStreamDestroy(r->ctl); r->ctl = nullptr; }      // (an abort writes into the contexts' ctrl[])
     for (auto& c : r->ctx) {
         if (c.stream) hipStreamSynchronize(c.stream);
+        if (c.abortDone) hipEventDestroy(c.abortDone);
         void* own[] = {c.dRqO[0], c.dRqO[1], c.dRqD[0], c.dRqD[1], c.dHit, c.dLight, c.dAcc, c.dSeeds, c.dCtrl, c.dSlow, c.dSpill};
         for (void* p : own) if (p) hipFree(p);
         if (c.resolved) hipEventDestroy(c.resolved);
@@ -1081,6 +1087,7 @@ static int build_renderer(const RtxSceneDesc* scene, const RtxConfig& cfg, const
         CREATE_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
         CREATE_HIP(hipEventCreateWithFlags(&c.resolved, hipEventDisableTiming));
         CREATE_HIP(hipEventCreateWithFlags(&c.countsReady, hipEventDisableTiming));
+        CREATE_HIP(hipEventCreateWithFlags(&c.abortDone, hipEventDisableTiming));
         CREATE_HIP(hipHostMalloc((void**)&c.hCounts, 8 * sizeof(uint32_t), hipHostMallocDefault));
         CREATE_HIP(hipMalloc((void**)&c.dCtrl, RTX_CTRL_WORDS * sizeof(uint32_t)));
         CREATE_HIP(hipMalloc((void**)&c.dStatsAhead, (size_t)RTX_AHEAD_MAX * RTX_STAT_WORDS * sizeof(unsigned long long)));
@@ -1096,6 +1103,13 @@ static int build_renderer(const RtxSceneDesc* scene, const RtxConfig& cfg, const
     r->aheadBatch = cfg.countStats ? 1 : std::min(r->batch, RTX_AHEAD_MAX);
     if (const char* e = getenv("RTX_AHEAD_BATCH")) r->aheadBatch = std::max(1, std::min(atoi(e), std::min(r->batch, RTX_AHEAD_MAX)));      // experiments
     if (cfg.worldSize != 1 && cfg.numDevices != -1) r->lookAhead = 0;       // a rank of a process group delivers through its own gather, once per batch (a device group looks ahead on all members)
+    if (r->lookAhead > 0 && !getenv("RTX_NO_ABORT")) {
+        // Streams of the highest priority draw their hardware queue from a pool of their own, so the control stream does not
+        // share a queue with a context that is busy with the very launches it is there to cut short.
+        int least = 0, greatest = 0;
+        CREATE_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        CREATE_HIP(hipStreamCreateWithPriority(&r->ctl, hipStreamNonBlocking, greatest));
+    }
     activate(r, 0);
     for (int b = 0; b < 4; ++b) r->queueHint[b] = r->numSlots * (uint32_t)r->batch;
     set_grids(r, r->numSlots * (uint32_t)r->batch);
@@ -1240,6 +1254,10 @@ static int render_batch(RtxRenderer* r, const std::pair<RtxCamera, uint32_t>* fr
         }
     }
     activate(r, (int)(r->frameSeq++ % r->ctx.size()));
+    if (r->ctx[r->active].abortPending) {      // the abort of the context's last set must have landed before ctrl[] is cleared for this one
+        HIP_TRY(hipStreamWaitEvent(r->stream, r->ctx[r->active].abortDone, 0));
+        r->ctx[r->active].abortPending = false;
+    }
     if (ahead) {
         r->curStats = r->ctx[r->active].dStatsAhead;
         HIP_TRY(hipMemsetAsync(r->curStats, 0, (size_t)RTX_AHEAD_MAX * RTX_STAT_WORDS * sizeof(unsigned long long), r->stream));
@@ -1327,9 +1345,38 @@ static int flush_queued(RtxRenderer* r) {
     return render_batch(r, q.data(), (int)q.size(), false);
 }
 
+// Sets started ahead that are not going to be asked for are made to run out at once instead of in full (up to three sets of
+// eight frames: 120 ms at 4K, behind which the frame the caller really asked for would wait). Every persistent kernel draws
+// its work through the work counters in its context's ctrl[] (WorkIter::next, the refills of the trace kernels) and a wave
+// stops drawing when a counter has passed the end of its queue segment — so the control stream overwrites ALL work counters
+// of the set's context (every launch of the set, started or not) with a value beyond any queue: waves finish the run they
+// hold, every later draw comes back empty, and the launches still queued find nothing to do (a few microseconds each).
+// Nothing the set wrote is ever read: only sets of which NO frame has been asked for are cut short (a frame that was taken
+// has its resolve queued behind the set's launches); their counters live in the context's own dStatsAhead, their queue
+// lengths are not used as hints. The context's next set waits for abortDone before it clears ctrl[] (render_batch).
+// kAbortValue + a segment's start + the draws that follow must stay below 2^32 (k_trace_qw adds the three): queues of up
+// to 2^30 entries qualify (a batch of 32 frames at 4K has 2^28), longer ones run out as before.
+static const uint32_t kAbortValue = 0x7fffff00u;
+static void abort_ahead(RtxRenderer* r) {
+    if (!r->ctl || r->ahead.empty()) return;
+    bool device = false;
+    for (const RtxRenderer::Ahead& a : r->ahead) {
+        if (a.index != 0 || a.ctx < 0) continue;          // frame 0 of a set is still waiting: no frame of that set was taken
+        RtxRenderer::FrameCtx& c = r->ctx[(size_t)a.ctx];
+        if ((uint64_t)r->numSlots * (uint64_t)std::max(1, c.capFrames) > 0x3fffffffull || c.abortPending) continue;
+        if (!device) { if (hipSetDevice(r->device) != hipSuccess) { (void)hipGetLastError(); return; } device = true; }
+        if (hipMemsetD32Async((hipDeviceptr_t)(c.dCtrl + RTX_CTRL_XWORK(0, 0)), (int)kAbortValue, RTX_CTRL_WORDS - RTX_CTRL_XWORK(0, 0), r->ctl) != hipSuccess ||
+            hipEventRecord(c.abortDone, r->ctl) != hipSuccess) { (void)hipGetLastError(); return; }      // (not cut short, then: the set runs out in full)
+        c.abortPending = true;
+        c.countsPending = false;       // queue lengths of a set that was cut short say nothing about the next one
+        r->abortedSets++;
+    }
+}
+static void clear_ahead(RtxRenderer* r) { abort_ahead(r); r->ahead.clear(); r->aheadNext = 1; }
+
 // every frame queued or in flight finished (the host-side entry points that touch the framebuffer start here)
 // frames started ahead are not going to be asked for (and the loop, if there was one, is over)
-static void drop_ahead(RtxRenderer* r) { r->ahead.clear(); r->aheadNext = 1; r->haveLast = false; r->streak = 0; r->rendersSinceDelivery = 0; }
+static void drop_ahead(RtxRenderer* r) { clear_ahead(r); r->haveLast = false; r->streak = 0; r->rendersSinceDelivery = 0; }
 
 // May another set be started ahead? Every set occupies a context until its last frame has been asked for (or all are
 // dropped); sets take the contexts in turn, so the next launch lands on the context of the oldest set. With a set
@@ -1359,7 +1406,8 @@ static int start_ahead(RtxRenderer* const* all, int n, const RtxCamera& cam, uin
 static int sync_all(RtxRenderer* r) {
     drop_ahead(r);
     if (flush_queued(r)) return 1;
-    for (auto& c : r->ctx) if (c.stream) HIP_TRY(hipStreamSynchronize(c.stream));
+    if (r->ctl) HIP_TRY(hipStreamSynchronize(r->ctl));      // (before the contexts: an abort is what lets their streams finish early)
+    for (auto& c : r->ctx) { if (c.stream) HIP_TRY(hipStreamSynchronize(c.stream)); c.abortPending = false; }
     return 0;
 }
 
@@ -1534,7 +1582,7 @@ int rtx_render(RtxRenderer* r, const RtxCamera* camera, uint32_t frameCounter, f
         const bool match = !r->ahead.empty() && r->ahead.front().fc == frameCounter && memcmp(camera, &r->ahead.front().cam, sizeof(RtxCamera)) == 0;
         for (RtxRenderer* m : all) {
             if (match && !m->ahead.empty()) { if (take_ahead(m)) return 1; continue; }
-            m->ahead.clear(); m->aheadNext = 1;
+            clear_ahead(m);
             if (!pixels_rgba && m->batch > 1) {
                 if (m->capFrames < m->batch && grow_queues(m)) return 1;      // the first queued frame: room for whole batches
                 m->queued.emplace_back(*camera, frameCounter);
@@ -1572,7 +1620,7 @@ static int render_one(RtxRenderer* r, const RtxCamera* camera, uint32_t frameCou
             if (take_ahead(r)) return 1;           // (nothing is collected at this point: frames are started ahead by a delivery, which renders the collection first)
             return pixels_rgba ? deliver(r, false, 0.0f, pixels_rgba) : 0;
         }
-        r->ahead.clear(); r->aheadNext = 1;        // started for nothing
+        clear_ahead(r);                            // started for nothing: cut short
     }
     if (!pixels_rgba && r->batch > 1) {
         // nothing has to be delivered yet: collect the frame; a full batch is rendered by one set of launches
@@ -1770,6 +1818,8 @@ int rtx_clear_pixels(RtxRenderer* r) {
 int rtx_get_info(RtxRenderer* r, RtxInfo* out) {
     if (!r || !out) return fail("NULL argument");
     *out = r->info;
+    out->setsCutShort = r->abortedSets;
+    for (const RtxRenderer* m : r->peers) out->setsCutShort += m->abortedSets;
     return 0;
 }
 

@@ -70,13 +70,13 @@ def test_ctypes_mirrors_of_config_info_counters_match_the_header(tmp_path):
     src = tmp_path / "sizes.c"
     src.write_text('#include "rtx.h"\n#include <stddef.h>\n#include <stdio.h>\n'
                    'int main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(RtxConfig), offsetof(RtxConfig, numDevices), offsetof(RtxConfig, lookAhead), '
-                   'offsetof(RtxConfig, framesPerBatch), sizeof(RtxInfo), offsetof(RtxInfo, lookAhead), sizeof(RtxCounters), offsetof(RtxCounters, wavePasses));return 0;}\n')
+                   'offsetof(RtxConfig, framesPerBatch), sizeof(RtxInfo), offsetof(RtxInfo, setsCutShort), sizeof(RtxCounters), offsetof(RtxCounters, wavePasses));return 0;}\n')
     exe = tmp_path / "sizes"
     subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(src)])      # the header is C
     got = [int(x) for x in subprocess.check_output([str(exe)], text=True).split()]
     C, I, K = _capi.Config, _capi.Info, _capi.Counters
     assert got == [ctypes.sizeof(C), C.numDevices.offset, C.lookAhead.offset, C.framesPerBatch.offset,
-                   ctypes.sizeof(I), I.lookAhead.offset, ctypes.sizeof(K), K.wavePasses.offset]
+                   ctypes.sizeof(I), I.setsCutShort.offset, ctypes.sizeof(K), K.wavePasses.offset]
 
 
 def test_hip_backend_has_no_cpu_fallback(monkeypatch):

@@ -578,6 +578,46 @@ def test_look_ahead_of_the_synchronous_loop_is_invisible(scene2, monkeypatch):
     check_fb(runs["2"][-2], want)
 
 
+def test_sets_started_for_nothing_are_cut_short_and_nobody_notices(monkeypatch):
+    """A caller that leaves the loop while sets of frames are ahead: the library overwrites the work counters of those sets
+    from a control stream so that their launches run out at once (rtx_api.hip abort_ahead; RtxInfo.setsCutShort counts them).
+    At 1920x1088 the sets are in the middle of their launches when the jump comes. Images and counters must be those of a
+    renderer that lets the sets run out (RTX_NO_ABORT=1), bit for bit — also for the frames that follow on the very contexts
+    whose sets were cut short (their next launches wait for the abort to land before they clear the counters) — and the
+    oracle's."""
+    from raytracer_amd.scene import synthetic_scene
+    s = synthetic_scene(200_000, 1920, 1080, seed=11, tex_size=64, nthreads=8)
+    d, cam = s.desc(), s.camera
+    # loop, jump, loop again at once (the contexts of the dropped sets are reused straight away), a queued batch, jump back
+    script = [("r", fc) for fc in range(10)] + [("r", 500)] + [("r", fc) for fc in range(501, 512)] + [("r", 40)] + \
+             [("q", fc) for fc in range(41, 47)] + [("r", 47), ("r", 48), ("r", 49), ("r", 3)]
+    runs = {}
+    for no_abort in (False, True):
+        if no_abort: monkeypatch.setenv("RTX_NO_ABORT", "1")
+        else: monkeypatch.delenv("RTX_NO_ABORT", raising=False)
+        r = HIPShader(s)
+        px = np.zeros((d.height, d.width, 4), np.float32)
+        log = []
+        for op, fc in script:
+            r.frame_counter = fc
+            r.Render(px if op == "r" else None)
+            if op == "r" and fc in (2, 9, 500, 501, 511, 40, 47, 49, 3): log.append(px.copy())
+        cut = r.info().setsCutShort
+        c = r.counters()
+        log.append(np.array([c.frames] + list(c.raysPerBounce) + list(c.hitsPerBounce), np.int64))
+        runs[no_abort] = (log, cut)
+        r.close()
+    monkeypatch.delenv("RTX_NO_ABORT", raising=False)
+    assert runs[True][1] == 0 and runs[False][1] >= 3, (runs[True][1], runs[False][1])      # three jumps, at least one untouched set each
+    for a, b in zip(runs[False][0], runs[True][0]):
+        assert (a.view(np.uint32) == b.view(np.uint32)).all()
+    assert runs[False][0][-1][0] == len(script)
+    want = np.zeros((d.height, d.width, 4), np.float32)
+    for fc in range(3):
+        oracle.render(d, cam, fc, want, 8)
+    check_fb(runs[False][0][0], want)
+
+
 def test_config_knobs_are_reported_and_do_not_change_results(scene1):
     """RtxConfig.framesPerBatch / lookAhead / framesInFlight as resolved by rtx_create (rtx_get_info), and the same image
     whatever they are."""
