@@ -163,10 +163,11 @@ typedef struct RtxConfig {
                               a row for (camera, n) and (camera, n + 1) — the reference's loop, src/WindowManager.cpp:
                               154-158 — it starts up to `lookAhead` SETS of following frames (everything but their update of
                               the running mean) before it copies the current one out; a set is one set of launches for 1, 2,
-                              then 4 consecutive frames (it grows while the loop lasts, so that a short loop or an early
+                              4, then 8 consecutive frames (it grows while the loop lasts, so that a short loop or an early
                               wrong guess wastes little), applied to the running mean one frame per call. The next call
-                              either asks for the first frame started ahead or they are all dropped unused. Images and work
-                              counters are the same either way; a wrong guess costs device time only (at most ~3 sets of up to 8 frames).
+                              either asks for the first frame started ahead or they are all dropped unused — and cut short:
+                              the library overwrites their work counters from a control stream, so their launches run out
+                              at once (RtxInfo.setsCutShort). Images and work counters are the same either way.
                               0 -> up to 3, at most framesInFlight - 1 (2 with HIP's default 4 hardware queues); -1 -> never.
                               A device group looks ahead on all its members. */
     int32_t framesPerBatch;/* frames queued with pixels_rgba == NULL are collected and rendered `framesPerBatch` at a time by
