@@ -75,9 +75,13 @@ def sync_only(args):
     scene = synthetic_scene(ntri, w, h, seed=12345, textured=textured, nthreads=16, grid=grid)
     trav = {"wide": _capi.TRAVERSE_WIDE, "culled": _capi.TRAVERSE_CULLED, "exact": _capi.TRAVERSE_EXACT}[args.traversal]
     res = {}
-    for key, look in (("no_look_ahead", -1), ("default", 0)):
+    for key, look in (("no_look_ahead", -1), ("default", 0), ("page_locked", 0)):
         shader = HIPShader(scene, device=0, traversal=trav, look_ahead=look)
         px = np.zeros((shader.height, shader.width, 4), dtype=np.float32)
+        if key == "page_locked":          # a caller that page-locks its pixel array gets the frame by one direct copy (rtx_api.hip deliver_bytes)
+            import torch
+            pinned = torch.zeros((shader.height, shader.width, 4), dtype=torch.float32).pin_memory()
+            px = pinned.numpy()
         warm = 12                               # the loop is recognised after two frames; the sets started ahead grow over the next few
         for i in range(warm):
             shader.frame_counter = i
@@ -119,7 +123,9 @@ def sync_only(args):
                     "the library overwrites the work counters of those sets so that their launches run out at once (rtx_api.hip abort_ahead); "
                     "sets_run_out = the same call with RTX_NO_ABORT=1")
     out = dict(res["default"])
-    out.update({"wrong_guess_ms": jump, "without_look_ahead": {"ms_per_step": res["no_look_ahead"]["ms_per_step"], "mrays_per_s": res["no_look_ahead"]["mrays_per_s"]},
+    out.update({"wrong_guess_ms": jump, "page_locked_destination": {"ms_per_step": res["page_locked"]["ms_per_step"], "mrays_per_s": res["page_locked"]["mrays_per_s"],
+                                                                    "note": "the same loop with the caller's pixel array page-locked: one direct device-to-host copy per frame, no staging"},
+                "without_look_ahead": {"ms_per_step": res["no_look_ahead"]["ms_per_step"], "mrays_per_s": res["no_look_ahead"]["mrays_per_s"]},
                 "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"),
                 "pattern": "rtx_render(pixels) per frame, synchronous, 16 B/pixel copied to a pageable host array every frame; "
                            "look_ahead = frames the library starts before they are asked for (RtxConfig.lookAhead, same results)"})

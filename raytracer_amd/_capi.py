@@ -150,6 +150,10 @@ def hip_lib():
             getattr(L, fn).argtypes = [C.c_void_p, C.c_void_p]
         L.rtx_clear_pixels.argtypes = [C.c_void_p]
         L.rtx_present_rgba8.argtypes = [C.c_void_p, C.c_float, C.c_void_p]
+        L.rtx_alloc_host.argtypes = [C.c_uint64]
+        L.rtx_alloc_host.restype = C.c_void_p
+        L.rtx_free_host.argtypes = [C.c_void_p]
+        L.rtx_free_host.restype = None
         L.rtx_get_counters.argtypes = [C.c_void_p, C.POINTER(Counters)]
         L.rtx_get_info.argtypes = [C.c_void_p, C.POINTER(Info)]
         L.rtx_reset_counters.argtypes = [C.c_void_p]
@@ -174,7 +178,7 @@ def hip_lib():
 
 
 EXPORTED_HIP = ["rtx_create", "rtx_render", "rtx_primary_hits", "rtx_trace_rays", "rtx_trace_rays_noalloc", "rtx_upload_pixels",
-                "rtx_download_pixels", "rtx_clear_pixels", "rtx_present_rgba8", "rtx_get_info", "rtx_get_counters", "rtx_reset_counters", "rtx_destroy",
+                "rtx_download_pixels", "rtx_clear_pixels", "rtx_present_rgba8", "rtx_alloc_host", "rtx_free_host", "rtx_get_info", "rtx_get_counters", "rtx_reset_counters", "rtx_destroy",
                 "rtx_last_error", "rtx_framebuffer_device_ptr", "rtx_stream", "rtx_local_pixel_count",
                 "rtx_local_tile_count", "rtx_packed_floats", "rtx_pack_tiles", "rtx_unpack_tiles", "rtx_version"]
 EXPORTED_HOST = ["rtxh_scene_new", "rtxh_scene_free", "rtxh_scene_set_resolution", "rtxh_scene_load_scn", "rtxh_scene_load_mtl",

@@ -25,7 +25,7 @@
 
 using namespace rtxhost;
 
-static void write_pfm(const char* path, const std::vector<Color>& px, uint32_t w, uint32_t h) {
+static void write_pfm(const char* path, const Color* px, uint32_t w, uint32_t h) {
     FILE* f = fopen(path, "wb");
     if (!f) { fprintf(stderr, "cannot write %s\n", path); return; }
     fprintf(f, "PF\n%u %u\n-1.0\n", w, h);
@@ -36,7 +36,7 @@ static void write_pfm(const char* path, const std::vector<Color>& px, uint32_t w
 
 // 24-bit BMP, bottom-up rows like the reference's y axis; gamma > 0 applies v^(1/gamma) first (the reference
 // carries gamma = 2.2 in its context, src/RenderingContext.h:48, but only the OpenCL display path uses it)
-static void write_bmp(const char* path, const std::vector<Color>& px, uint32_t w, uint32_t h, float gamma) {
+static void write_bmp(const char* path, const Color* px, uint32_t w, uint32_t h, float gamma) {
     FILE* f = fopen(path, "wb");
     if (!f) { fprintf(stderr, "cannot write %s\n", path); return; }
     const uint32_t row = (w * 3 + 3) & ~3u, size = 54 + row * h;
@@ -113,7 +113,14 @@ int main(int argc, char** argv) {
     FillContext(context, scene);
     context.numBoundedFrames = (uint32_t)frames;
     printf("Resolution : %d x %d\n", context.width, context.height);
-    std::vector<Color> pixels((size_t)context.width * context.height, Color{0, 0, 0, 0});   // src/WindowManager.cpp:26-27
+    // src/WindowManager.cpp:26-27 (`pixels = new Color[w * h]`, zero-filled) — in page-locked memory, so that every frame lands in
+    // it by one direct copy (include/rtx.h rtx_alloc_host); RTX_SHADER_PAGEABLE=1 keeps the reference's ordinary array
+    const size_t numPixels = (size_t)context.width * context.height;
+    std::vector<Color> pageable;
+    Color* locked = getenv("RTX_SHADER_PAGEABLE") ? nullptr : (Color*)rtx_alloc_host(numPixels * sizeof(Color));
+    if (!locked) pageable.assign(numPixels, Color{0, 0, 0, 0});
+    else memset(locked, 0, numPixels * sizeof(Color));
+    Color* const pixels = locked ? locked : pageable.data();
 
     RtxConfig cfg; memset(&cfg, 0, sizeof(cfg));
     if (gpus > 1) {
@@ -146,7 +153,7 @@ int main(int argc, char** argv) {
                 fprintf(stderr, "present: %s\n", rtx_last_error()); return -1;
             }
         } else {
-            service->Render(pixels.data());                 // src/WindowManager.cpp:156
+            service->Render(pixels);                 // src/WindowManager.cpp:156
         }
         context.frameCounter++;                             // :157
         auto t1 = std::chrono::steady_clock::now();
@@ -181,6 +188,7 @@ int main(int argc, char** argv) {
         else write_pfm(outPath, pixels, context.width, context.height);
     }
     delete service;
+    if (locked) rtx_free_host(locked);
     rtxh_scene_free(scene);
     return 0;
 }

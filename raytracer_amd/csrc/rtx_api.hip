@@ -1461,12 +1461,27 @@ static int stage_deliver(RtxRenderer* r, char* dst, size_t bytes) {
     return 0;
 }
 
-// device array of this renderer -> caller's (pageable) host array
-static int dev_to_host(RtxRenderer* r, const void* devSrc, void* hostDst, size_t bytes) {
-    if (bytes >= kStagePiece && !getenv("RTX_PLAIN_COPY")) {
-        if (stage_queue(r, r->stream, (const char*)devSrc, bytes)) return 1;
-        return stage_deliver(r, (char*)hostDst, bytes);
+// A caller's array that is page-locked (hipHostMalloc, hipHostRegister, a pinned tensor) takes the copy directly: the DMA
+// engine writes it at the link's rate and no host thread touches the bytes.
+static bool host_is_page_locked(const void* p) {
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }      // ordinary memory: "invalid value", not an error of ours
+    return a.type == hipMemoryTypeHost;
+}
+// src[0, bytes) on the device -> dst on the host, behind whatever `stream` holds; returns when the bytes are there
+static int deliver_bytes(RtxRenderer* r, hipStream_t stream, const char* src, char* dst, size_t bytes) {
+    if (host_is_page_locked(dst)) {
+        HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        return 0;
     }
+    if (stage_queue(r, stream, src, bytes)) return 1;
+    return stage_deliver(r, dst, bytes);
+}
+
+// device array of this renderer -> caller's host array
+static int dev_to_host(RtxRenderer* r, const void* devSrc, void* hostDst, size_t bytes) {
+    if (bytes >= kStagePiece && !getenv("RTX_PLAIN_COPY")) return deliver_bytes(r, r->stream, (const char*)devSrc, (char*)hostDst, bytes);
     HIP_TRY(hipMemcpyAsync(hostDst, devSrc, bytes, hipMemcpyDeviceToHost, r->stream));
     HIP_TRY(hipStreamSynchronize(r->stream));
     return 0;
@@ -1560,8 +1575,7 @@ static int deliver(RtxRenderer* r, bool present, float gamma, void* dst) {
     r->rendersSinceDelivery = 0;
     while (loop && may_start_ahead(r))
         if (start_ahead(&r, 1, r->lastCam, r->lastFc + 1u + (uint32_t)r->ahead.size())) return 1;
-    if (stage_queue(r, ds, src, bytes)) return 1;
-    return stage_deliver(r, (char*)dst, bytes);
+    return deliver_bytes(r, ds, src, (char*)dst, bytes);
 }
 
 static int render_one(RtxRenderer* r, const RtxCamera* camera, uint32_t frameCounter, float* pixels_rgba);
@@ -1598,8 +1612,7 @@ int rtx_render(RtxRenderer* r, const RtxCamera* camera, uint32_t frameCounter, f
             if (start_ahead(all.data(), (int)all.size(), *camera, frameCounter + 1u + (uint32_t)r->ahead.size())) return 1;
         HIP_TRY(hipSetDevice(r->device));
         const size_t bytes = (size_t)r->width * r->height * sizeof(float4);
-        if (stage_queue(r, ls, (const char*)r->dFb, bytes)) return 1;
-        return stage_deliver(r, (char*)pixels_rgba, bytes);
+        return deliver_bytes(r, ls, (const char*)r->dFb, (char*)pixels_rgba, bytes);
     }
     // device group: the frame is queued on every member (their launches run side by side on their devices) ...
     if (render_one(r, camera, frameCounter, nullptr)) return 1;
@@ -1814,6 +1827,14 @@ int rtx_clear_pixels(RtxRenderer* r) {
     HIP_TRY(hipStreamSynchronize(r->stream));      // frames on the other streams must not overtake the clear
     return 0;
 }
+
+void* rtx_alloc_host(uint64_t bytes) {
+    void* p = nullptr;
+    const hipError_t e = hipHostMalloc(&p, (size_t)std::max<uint64_t>(bytes, 1), hipHostMallocDefault);
+    if (e != hipSuccess) { (void)hipGetLastError(); fail(std::string("rtx_alloc_host: ") + hipGetErrorString(e)); return nullptr; }
+    return p;
+}
+void rtx_free_host(void* p) { if (p && hipHostFree(p) != hipSuccess) (void)hipGetLastError(); }
 
 int rtx_get_info(RtxRenderer* r, RtxInfo* out) {
     if (!r || !out) return fail("NULL argument");

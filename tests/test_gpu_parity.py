@@ -618,6 +618,48 @@ def test_sets_started_for_nothing_are_cut_short_and_nobody_notices(monkeypatch):
     check_fb(runs[False][0][0], want)
 
 
+def test_page_locked_destination_takes_the_frame_directly():
+    """A caller's array that is page-locked (here: a pinned torch tensor seen through numpy) receives the frame by one
+    direct device-to-host copy instead of the staged copy for pageable memory (rtx_api.hip deliver_bytes) — same bytes,
+    through the synchronous loop with its look-ahead, through rtx_download_pixels, as a device group, and into memory from
+    rtx_alloc_host."""
+    import torch
+    from raytracer_amd.scene import synthetic_scene
+    s = synthetic_scene(20_000, 1280, 704, seed=3, tex_size=64, nthreads=8)       # 14.4 MB per frame: above the staging threshold
+    d = s.desc()
+    pinned = torch.empty((d.height, d.width, 4), dtype=torch.float32).pin_memory()
+    assert pinned.is_pinned()
+    out = {}
+    # ... and an array from the library's own rtx_alloc_host (what a maintainer would put in place of `new Color[w * h]`)
+    L = _capi.hip_lib()
+    nbytes = d.height * d.width * 16
+    mem = L.rtx_alloc_host(nbytes)
+    assert mem, "rtx_alloc_host failed"
+    import ctypes
+    own = np.ctypeslib.as_array(ctypes.cast(mem, ctypes.POINTER(ctypes.c_float)), shape=(d.height, d.width, 4))
+    for kind in ("pageable", "pinned", "pinned group", "rtx_alloc_host"):
+        r = HIPShader(s, devices=[0, 0]) if kind.endswith("group") else HIPShader(s)
+        px = np.zeros((d.height, d.width, 4), np.float32) if kind == "pageable" else (own if kind == "rtx_alloc_host" else pinned.numpy())
+        px[...] = 0
+        log = []
+        for fc in range(6):
+            r.frame_counter = fc; r.Render(px)
+            log.append(px.copy())
+        r.frame_counter = 6; r.Render(None)
+        r.download_into(px); log.append(px.copy())
+        out[kind] = log
+        r.close()
+    del own
+    L.rtx_free_host(mem)
+    for kind in ("pinned", "pinned group", "rtx_alloc_host"):
+        for a, b in zip(out["pageable"], out[kind]):
+            assert (a.view(np.uint32) == b.view(np.uint32)).all(), kind
+    want = np.zeros((d.height, d.width, 4), np.float32)
+    for fc in range(2):
+        oracle.render(d, s.camera, fc, want, 8)
+    check_fb(out["pinned"][1], want)
+
+
 def test_config_knobs_are_reported_and_do_not_change_results(scene1):
     """RtxConfig.framesPerBatch / lookAhead / framesInFlight as resolved by rtx_create (rtx_get_info), and the same image
     whatever they are."""
